@@ -1,0 +1,146 @@
+"""Generate golden vectors for the HE-CKA hot path FROM THE REAL REFERENCE.
+
+Run only in the build container (needs /root/reference, which never travels):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+It imports the reference's own `hyper.diversity.model_kernels` (with the two harness-side
+shims SURVEY.md 8c lists: `collections.Callable` for Python >= 3.10 and stub modules for
+absent third-party packages), builds each model kernel with the reference's
+`build_model_kernel` from a YAML-shaped dict, runs forward + autograd backward on seeded
+inputs and stores inputs and outputs as arrays in `tests/golden/<case>.npz`.  The fixtures
+hold data only (inputs, expected outputs, the config dict as JSON) - no reference source.
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    collections.Callable = collections.abc.Callable
+    for name, attrs in {
+        'torchmetrics': ['Accuracy'],
+        'x_transformers': ['TransformerWrapper', 'Decoder'],
+        'x_transformers.x_transformers': ['AttentionLayers', 'ScaledSinusoidalEmbedding', 'AbsolutePositionalEmbedding'],
+        'positional_encodings': [],
+        'positional_encodings.torch_encodings': ['PositionalEncoding1D', 'Summer'],
+    }.items():
+        mod = types.ModuleType(name)
+        for a in attrs:
+            setattr(mod, a, type(a, (), {}))
+        sys.modules.setdefault(name, mod)
+    sys.path.insert(0, REF)
+    import hyper.diversity.model_kernels as mk
+    return mk
+
+
+def he(kernel='linear', detach_diag=True, params=None, **kw):
+    fk = {'name': 'feature', 'kernel': kernel, 'detach_diag': detach_diag}
+    if params:
+        fk['params'] = params
+    return dict(name='he', feature_kernel=fk, **kw)
+
+
+def cka(kernel='linear', detach_diag=True, params=None, **kw):
+    fk = {'name': 'feature', 'kernel': kernel, 'detach_diag': detach_diag}
+    if params:
+        fk['params'] = params
+    return dict(name='cka', feature_kernel=fk, **kw)
+
+
+def layers(layer_kernel, weighting, reduction='mean'):
+    return {'name': 'model_layers', 'layer_kernel': layer_kernel, 'layer_weighting': weighting, 'reduction': reduction}
+
+
+MNIST_W = {'name': 'start_end_linear', 'first_layer': 0.387, 'middle_start': 0.746, 'middle_increase': 1.267, 'last_layer': 3.63}
+UNI = {'name': 'uniform'}
+
+# name -> (config, M, B, feature shapes per layer, input style)
+CASES = {
+    'he_lin_mnist': (layers(he(eps=0.0025, arc_eps=0.031), MNIST_W), 5, 12, [(6, 3, 3), (16,), (12,), (8,), (10,)], 'randn'),
+    'he_lin_exp_cifar': (layers(he(eps=0.001, arc_eps=0.001, use_exp=True),
+                                {'name': 'list', 'weights': [0.0, 0.15, 0.25, 0.0001], 'normalize': False}),
+                         4, 9, [(4, 2, 2), (7,), (33,), (10,)], 'relu'),
+    'he_lin_s0': (layers(he(he_s=0.0, eps=1e-3, arc_eps=1e-2), UNI), 4, 8, [(5,), (24,)], 'randn'),
+    'he_lin_s1': (layers(he(he_s=1.0, eps=1e-3, arc_eps=1e-2), UNI), 4, 8, [(5,), (24,)], 'randn'),
+    'he_lin_s3_abs': (layers(he(he_s=3.0, eps=1e-5, arc_eps=3e-3, abs_vals=True), {'name': 'linear', 'start_weight': 1.0, 'weight_increase': 0.5}),
+                      6, 16, [(24,), (7,)], 'randn'),
+    'he_lin_detach_right_sum': (layers(he(eps=1e-3, arc_eps=1e-2, detach_right=True), {'name': 'exponential', 'start_weight': 0.5, 'weight_increase': 2.0}, 'sum'),
+                                5, 10, [(9,), (17,)], 'randn'),
+    'he_lin_nodetach': (layers(he(detach_diag=False, eps=1e-4, arc_eps=1e-3), UNI), 4, 8, [(11,)], 'randn'),
+    'he_lin_none': (layers(he(eps=0.001, arc_eps=0.001, detach_right=True, reduction='none'), UNI, 'none'), 5, 8, [(6,), (20,)], 'randn'),
+    'he_lin_correlated': (layers(he(eps=0.0025, arc_eps=0.031), UNI), 6, 16, [(32,), (64,)], 'correlated'),
+    'he_lin_odd': (layers(he(eps=0.0025, arc_eps=0.031), UNI), 3, 37, [(19,), (130,)], 'randn'),
+    'he_lin_bench_small': (layers(he(eps=0.0025, arc_eps=0.031), UNI), 6, 64, [(32,), (72,)], 'randn'),
+    'cka_lin': (layers(cka(eps=1e-6), UNI), 5, 10, [(9,), (17,)], 'randn'),
+    'cka_lin_none': (layers(cka(eps=1e-6, detach_right=True, reduction='none'), {'name': 'list', 'weights': [0.4, 0.6], 'normalize': False}, 'none'),
+                     5, 10, [(9,), (17,)], 'randn'),
+    'he_cossim': (layers(he('cossim', eps=0.0025, arc_eps=0.031), UNI), 5, 12, [(16,), (10,)], 'randn'),
+    'he_rbf_toy': (layers(he('rbf', he_s=5.0, eps=0.000005, arc_eps=0.00305, params={'param': 5.025}),
+                          {'name': 'list', 'weights': [0.05, 0.35, 1.0, 0.85]}), 6, 10, [(30,), (40,), (30,), (4,)], 'randn'),
+    'cka_rbf': (layers(cka('rbf', params={'param': 1.5}), UNI), 4, 9, [(7,)], 'randn'),
+}
+
+
+def make_inputs(style, M, B, shapes, gen):
+    xs = []
+    for shp in shapes:
+        x = torch.randn(M, B, *shp, generator=gen, dtype=torch.float64)
+        if style == 'relu':
+            x = torch.relu(x + 0.3)
+        elif style == 'correlated':
+            x = 0.7 * torch.randn(1, B, *shp, generator=gen, dtype=torch.float64) + 0.3 * x
+        xs.append(x)
+    return xs
+
+
+def run_case(mk, name, cfg, M, B, shapes, style, dtype):
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    xs64 = make_inputs(style, M, B, shapes, gen)
+    # the reference mutates a module-global default dict (model_kernels.py:78-80): reset it per case
+    from hyper.diversity import kernels as rk
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    rk.KERN_PARAMS['cossim'] = {'eps': 1e-6}
+    kern = mk.build_model_kernel(cfg).to(dtype)
+    xs = [x.to(dtype).requires_grad_(True) for x in xs64]
+    feats = collections.OrderedDict((str(i), x) for i, x in enumerate(xs))
+    track = collections.OrderedDict()
+    out = kern(None, feats, None, track)
+    if out.ndim == 0:
+        up = None
+        out.backward()
+    else:
+        up = torch.randn(out.shape, generator=gen, dtype=torch.float64).to(dtype)
+        (out * up).sum().backward()
+    rec = {'config': json.dumps(cfg), 'M': M, 'B': B, 'style': style, 'out': out.detach().numpy()}
+    if up is not None:
+        rec['upstream'] = up.numpy()
+    for i, x in enumerate(xs):
+        rec['x%d' % i] = x.detach().numpy()
+        rec['dx%d' % i] = x.grad.numpy()
+        rec['gram%d' % i] = track['layer_track'][i]['gram'].detach().numpy()
+    return rec
+
+
+def main():
+    mk = _import_reference()
+    for name, (cfg, M, B, shapes, style) in CASES.items():
+        for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+            rec = run_case(mk, name, cfg, M, B, shapes, style, dtype)
+            if name == 'he_lin_bench_small':   # keep the big one small on disk
+                rec = {k: v for k, v in rec.items() if not k.startswith('gram')}
+            np.savez_compressed(os.path.join(OUT, '%s_%s.npz' % (name, tag)), **rec)
+            print(name, tag, 'out', np.asarray(rec['out']).reshape(-1)[:3])
+
+
+if __name__ == '__main__':
+    main()
