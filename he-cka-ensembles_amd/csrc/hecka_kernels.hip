@@ -1,0 +1,469 @@
+// libhecka: HIP kernels (gfx950) + C-ABI for the HE-CKA diversity-loss hot path.
+// See include/hecka.h for the contract of every entry point and DESIGN.md for the data layout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/hecka.h"
+#include "gemm_mfma.hpp"
+
+namespace hecka {
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* fmt, const char* a = "", long long x = 0, long long y = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, x, y);
+  return code;
+}
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HECKA_ELAUNCH, "%s: launch failed (%lld)", what, (long long)e);
+  return HECKA_OK;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------
+// (1) column mean: sbar[m,p] = mean_b X[m,b,p].   HBM-bound: reads X once (4 B / element).
+// Block = 32 float4-columns x 16 row-slices (512 threads); grid (ceil(P/128), M).
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
+                                                      float* __restrict__ sbar) {
+  __shared__ f32x4 red[16][32];
+  const int m = blockIdx.y;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int p = (blockIdx.x * 32 + cx) * 4;
+  const float* Xm = X + (size_t)m * B * P;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (p < P) {
+    if (VEC) {
+#pragma unroll 8
+      for (int b = ry; b < B; b += 16) acc += *reinterpret_cast<const f32x4*>(Xm + (size_t)b * P + p);
+    } else {
+      for (int b = ry; b < B; b += 16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (p + e < P) acc[e] += Xm[(size_t)b * P + p + e];
+    }
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && p < P) {
+    f32x4 s = red[0][cx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) s += red[r][cx];
+    const float inv = 1.0f / (float)B;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (p + e < P) sbar[(size_t)m * P + p + e] = s[e] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// (2) centred symmetric Gram.  MFMA-bound: 2*B*B*P flop per member (upper-triangular tiles only).
+// ------------------------------------------------------------------------------------------
+template <int TM, bool VEC>
+struct CenterPro {
+  const float* sbar;  // this member's column means [P]
+  int rows;           // B
+  float ca[TM / 32], cb[TM / 32];
+  __device__ __forceinline__ f32x4 mean4(int k, int kend) const {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      if (k < kend) s = *reinterpret_cast<const f32x4*>(sbar + k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < kend) s[e] = sbar[k + e];
+    }
+    return s;
+  }
+  __device__ __forceinline__ void stageA(f32x4& v, int i, int row, int k, int kend) {
+    if (row < rows) {
+      const f32x4 s = mean4(k, kend);
+      v -= s;
+      ca[i] += v[0] * s[0] + v[1] * s[1] + v[2] * s[2] + v[3] * s[3];
+    }
+  }
+  __device__ __forceinline__ void stageB(f32x4& v, int i, int row, int k, int kend) {
+    if (row < rows) {
+      const f32x4 s = mean4(k, kend);
+      v -= s;
+      cb[i] += v[0] * s[0] + v[1] * s[1] + v[2] * s[2] + v[3] * s[3];
+    }
+  }
+};
+
+template <int T, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void gram_center_kernel(GemmOperands g, const float* __restrict__ sbar,
+                                                                  float* __restrict__ C, float* __restrict__ cvec,
+                                                                  int ntile) {
+  using Tile = GemmTile<T, T, false, VEC, CenterPro<T, VEC>>;
+  __shared__ typename Tile::Smem sm;
+  __shared__ float cA[T], cB[T];
+
+  // decode upper-triangular tile pair (I <= J) from blockIdx.x
+  int I = 0, rem = blockIdx.x;
+  while (rem >= ntile - I) {
+    rem -= ntile - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const int m = blockIdx.y;
+  const int B = g.rowsA, P = g.K;
+  const float* Xm = g.A + (size_t)m * g.strideA;
+
+  CenterPro<T, VEC> pro;
+  pro.sbar = sbar + (size_t)m * P;
+  pro.rows = B;
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) pro.ca[i] = pro.cb[i] = 0.f;
+
+  Tile tile;
+  tile.run(sm, g, Xm, Xm, I * T, J * T, 0, P, pro);
+
+  // c_b = sbar . (x_b - sbar): finish the per-row dots (8 consecutive lanes share a staged row)
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    float a = pro.ca[i], b = pro.cb[i];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if ((threadIdx.x & 7) == 0) {
+      const int r = ((threadIdx.x + kThreads * i) >> 3);
+      cA[r] = a;
+      cB[r] = b;
+    }
+  }
+  __syncthreads();
+
+  float* Cm = C + (size_t)m * B * B;
+  const int row0 = I * T, col0 = J * T;
+  if (I == J && threadIdx.x < T && row0 + (int)threadIdx.x < B) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
+
+  tile.for_each([&](int lr, int lc, float v) {
+    const int row = row0 + lr, col = col0 + lc;
+    if (row < B && col < B) {
+      Cm[(size_t)row * B + col] = v + cB[lc];               // C[a,b] = Kt[a,b] + c[b]
+      if (I != J) Cm[(size_t)col * B + row] = v + cA[lr];   // mirrored tile: C[b,a] = Kt[a,b] + c[a]
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// (3) pairwise S = Ca Cb^T, split-K partials + fixed-order reduction.  HBM-bound: reads C once.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, float* __restrict__ part, int tilesN) {
+  using Tile = GemmTile<64, 64, false, VEC, NoPrologue>;
+  __shared__ typename Tile::Smem sm;
+  const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
+  const int z = blockIdx.z;
+  const long long kbeg = (long long)z * g.kchunk;
+  long long kend = kbeg + g.kchunk;
+  if (kend > g.K) kend = g.K;
+  NoPrologue pro;
+  Tile tile;
+  tile.run(sm, g, g.A, g.B, ti * 64, tj * 64, (int)kbeg, (int)kend, pro);
+  float* out = part + (size_t)z * g.rowsA * g.colsB;
+  const bool any = kend > kbeg;
+  tile.for_each([&](int lr, int lc, float v) {
+    const int row = ti * 64 + lr, col = tj * 64 + lc;
+    if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = any ? v : 0.f;
+  });
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int n, float* __restrict__ S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
+  S[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// (4) gamma = A cvec  (tiny)
+// ------------------------------------------------------------------------------------------
+__global__ void coef_gamma_kernel(const float* __restrict__ A, const float* __restrict__ cvec, int Ma, int Mb, int B,
+                                  float* __restrict__ gamma) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int j = 0; j < Mb; ++j) s += A[(size_t)i * Mb + j] * cvec[(size_t)j * B + b];
+  gamma[(size_t)i * B + b] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// (5) combine: W_i = 2 sum_j A_ij C_j + gamma_i 1^T - 1 gamma_i^T, diag masked.  HBM-bound.
+// ------------------------------------------------------------------------------------------
+// MODE 0: plain row mix  out = A V   (backward of the generic pairwise inner product)
+// MODE 1: symmetrised Gram gradient W (above)
+template <bool VEC, int MODE>
+__global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, const float* __restrict__ gamma, int B,
+                                                              int detach_diag, float* __restrict__ W, int tilesN) {
+  using Tile = GemmTile<64, 128, true, VEC, NoPrologue>;
+  __shared__ typename Tile::Smem sm;
+  const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
+  NoPrologue pro;
+  Tile tile;
+  tile.run(sm, g, g.A, g.B, ti * 64, tj * 128, 0, g.K, pro);
+  tile.for_each([&](int lr, int lc, float v) {
+    const int i = ti * 64 + lr;
+    const int n = tj * 128 + lc;
+    if (i < g.rowsA && n < g.colsB) {
+      float w = v;
+      if (MODE == 1) {
+        const int a = n / B, b = n - a * B;
+        w = 2.f * v + gamma[(size_t)i * B + a] - gamma[(size_t)i * B + b];
+        if (detach_diag && a == b) w = 0.f;
+      }
+      W[(size_t)i * g.colsB + n] = w;
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// (6) dX_m = W_m X_m.  MFMA-bound: 2*B*B*P flop per member.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, float* __restrict__ dX, int tilesN) {
+  using Tile = GemmTile<128, 128, true, VEC, NoPrologue>;
+  __shared__ typename Tile::Smem sm;
+  const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
+  const int m = blockIdx.y;
+  NoPrologue pro;
+  Tile tile;
+  tile.run(sm, g, g.A + (size_t)m * g.strideA, g.B + (size_t)m * g.strideB, ti * 128, tj * 128, 0, g.K, pro);
+  float* out = dX + (size_t)m * g.rowsA * g.colsB;
+  tile.for_each([&](int lr, int lc, float v) {
+    const int row = ti * 128 + lr, col = tj * 128 + lc;
+    if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = v;
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// (7) row-wise helpers for the un-fused functional API (center_gram and its backward).
+//     HBM-bound elementwise passes over [rows, cols].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_rows_kernel(const float* __restrict__ V, int cols, float* __restrict__ out,
+                                                          float* __restrict__ mean_out) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  const float* v = V + row * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += v[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)cols;
+  if (mean_out && threadIdx.x == 0) mean_out[row] = mean;
+  if (out)
+    for (int c = threadIdx.x; c < cols; c += 256) out[row * cols + c] = v[c] - mean;
+}
+
+// W[m,a,b] = G[m,a,b] + G[m,b,a]  (diag -> 0 when detach_diag): gradient of a symmetric-argument Gram
+__global__ __launch_bounds__(256) void symmetrize_kernel(const float* __restrict__ G, int B, int detach_diag,
+                                                         float* __restrict__ W) {
+  __shared__ float t[32][33];
+  const int m = blockIdx.z;
+  const float* g = G + (size_t)m * B * B;
+  float* w = W + (size_t)m * B * B;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8) {  // tile (b0.., a0..) read row-wise, kept transposed
+    const int rr = b0 + r, cc = a0 + tx;
+    t[r][tx] = (rr < B && cc < B) ? g[(size_t)rr * B + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int a = a0 + r, b = b0 + tx;
+    if (a < B && b < B) {
+      float v = g[(size_t)a * B + b] + t[tx][r];
+      if (detach_diag && a == b) v = 0.f;
+      w[(size_t)a * B + b] = v;
+    }
+  }
+}
+
+static int pairwise_nsplit(int Ma, int Mb, long long K) {
+  const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
+  const long long ktiles = (K + kBK - 1) / kBK;
+  long long want = (1024 + tiles - 1) / tiles;        // ~4 workgroups per CU in flight
+  long long maxs = (ktiles + 7) / 8;                  // at least 8 K-tiles (256 k) per workgroup
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+}  // namespace hecka
+
+using namespace hecka;
+
+extern "C" {
+
+int hecka_version(void) { return 1; }
+const char* hecka_last_error(void) { return g_err; }
+
+int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream) {
+  if (!X || !sbar) return fail(HECKA_EINVAL, "colmean: null pointer%s");
+  if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "colmean: non-positive size%s");
+  if (M > 65535) return fail(HECKA_EINVAL, "colmean: M > 65535%s");
+  const bool vec = (P % 4 == 0) && aligned16(X);
+  dim3 grid((P + 127) / 128, M);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(colmean_kernel<true>, grid, dim3(512), 0, st, X, B, P, sbar);
+  else
+    hipLaunchKernelGGL(colmean_kernel<false>, grid, dim3(512), 0, st, X, B, P, sbar);
+  return check_launch("colmean");
+}
+
+int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P, float* C, float* cvec,
+                          void* stream) {
+  if (!X || !sbar || !C || !cvec) return fail(HECKA_EINVAL, "gram_center: null pointer%s");
+  if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_center: non-positive size%s");
+  if (M > 65535) return fail(HECKA_EINVAL, "gram_center: M > 65535%s");
+  GemmOperands g;
+  g.A = X; g.B = X;
+  g.strideA = g.strideB = (long long)B * P;
+  g.lda = g.ldb = P;
+  g.rowsA = B; g.colsB = B;
+  g.K = P; g.kchunk = P;
+  const bool vec = (P % 4 == 0) && aligned16(X) && aligned16(sbar);
+  hipStream_t st = (hipStream_t)stream;
+  const int T = 128;
+  const int ntile = (B + T - 1) / T;
+  dim3 grid(ntile * (ntile + 1) / 2, M);
+  if (vec)
+    hipLaunchKernelGGL((gram_center_kernel<128, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
+  else
+    hipLaunchKernelGGL((gram_center_kernel<128, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
+  return check_launch("gram_center");
+}
+
+size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {
+  if (Ma <= 0 || Mb <= 0 || K <= 0) return 0;
+  return (size_t)pairwise_nsplit(Ma, Mb, K) * Ma * Mb * sizeof(float);
+}
+
+int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* ws,
+                       size_t ws_bytes, void* stream) {
+  if (!Ca || !Cb || !S || !ws) return fail(HECKA_EINVAL, "pairwise: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise: non-positive size%s");
+  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "pairwise: K too large (%lld)%s", "", K);
+  const int nsplit = pairwise_nsplit(Ma, Mb, K);
+  if (ws_bytes < (size_t)nsplit * Ma * Mb * sizeof(float))
+    return fail(HECKA_EWORKSPACE, "pairwise: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  GemmOperands g;
+  g.A = Ca; g.B = Cb;
+  g.strideA = g.strideB = 0;
+  g.lda = g.ldb = (int)K;
+  g.rowsA = Ma; g.colsB = Mb;
+  g.K = (int)K;
+  const long long ktiles = (K + kBK - 1) / kBK;
+  g.kchunk = (int)(((ktiles + nsplit - 1) / nsplit) * kBK);
+  const bool vec = (K % 4 == 0) && aligned16(Ca) && aligned16(Cb);
+  const int tilesM = (Ma + 63) / 64, tilesN = (Mb + 63) / 64;
+  dim3 grid(tilesM * tilesN, 1, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+  if (vec)
+    hipLaunchKernelGGL(pairwise_kernel<true>, grid, dim3(kThreads), 0, st, g, part, tilesN);
+  else
+    hipLaunchKernelGGL(pairwise_kernel<false>, grid, dim3(kThreads), 0, st, g, part, tilesN);
+  int rc = check_launch("pairwise");
+  if (rc) return rc;
+  const int n = Ma * Mb;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, nsplit, n, S);
+  return check_launch("pairwise_reduce");
+}
+
+int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int B, float* gamma, void* stream) {
+  if (!A || !cvec || !gamma) return fail(HECKA_EINVAL, "coef_gamma: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || B <= 0 || Ma > 65535) return fail(HECKA_EINVAL, "coef_gamma: bad size%s");
+  hipLaunchKernelGGL(coef_gamma_kernel, dim3((B + 255) / 256, Ma), dim3(256), 0, (hipStream_t)stream, A, cvec, Ma, Mb,
+                     B, gamma);
+  return check_launch("coef_gamma");
+}
+
+static int combine_impl(const float* A, const float* C, const float* gamma, int Ma, int Mb, long long N, int B,
+                        int detach_diag, float* W, void* stream, int mode) {
+  if (!A || !C || !W || (mode == 1 && !gamma)) return fail(HECKA_EINVAL, "combine: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || N <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
+  if (N > 0x7fffffffLL - 128) return fail(HECKA_EINVAL, "combine: row length too large%s");
+  GemmOperands g;
+  g.A = A; g.B = C;
+  g.strideA = g.strideB = 0;
+  g.lda = Mb; g.ldb = (int)N;
+  g.rowsA = Ma; g.colsB = (int)N;
+  g.K = Mb; g.kchunk = Mb;
+  const bool vec = (Mb % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(C);
+  const int tilesM = (Ma + 63) / 64, tilesN = (int)((N + 127) / 128);
+  dim3 grid(tilesM * tilesN);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1) {
+    if (vec)
+      hipLaunchKernelGGL((combine_kernel<true, 1>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+    else
+      hipLaunchKernelGGL((combine_kernel<false, 1>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+  } else {
+    if (vec)
+      hipLaunchKernelGGL((combine_kernel<true, 0>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+    else
+      hipLaunchKernelGGL((combine_kernel<false, 0>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+  }
+  return check_launch("combine");
+}
+
+int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B, int detach_diag,
+                      float* W, void* stream) {
+  if (B <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
+  return combine_impl(A, C, gamma, Ma, Mb, (long long)B * B, B, detach_diag, W, stream, 1);
+}
+
+int hecka_rowmix_f32(const float* A, const float* V, int Ma, int Mb, long long K, float* out, void* stream) {
+  return combine_impl(A, V, nullptr, Ma, Mb, K, 1, 0, out, stream, 0);
+}
+
+int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, float* mean, void* stream) {
+  if (!V || (!out && !mean)) return fail(HECKA_EINVAL, "center_rows: null pointer%s");
+  if (rows <= 0 || cols <= 0 || rows > 0x7fffffffLL) return fail(HECKA_EINVAL, "center_rows: bad size%s");
+  hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, V, cols, out, mean);
+  return check_launch("center_rows");
+}
+
+int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W, void* stream) {
+  if (!G || !W) return fail(HECKA_EINVAL, "symmetrize: null pointer%s");
+  if (M <= 0 || B <= 0 || M > 65535) return fail(HECKA_EINVAL, "symmetrize: bad size%s");
+  if (G == W) return fail(HECKA_EINVAL, "symmetrize: in-place not supported%s");
+  const int nt = (B + 31) / 32;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nt, nt, M), dim3(256), 0, (hipStream_t)stream, G, B, detach_diag, W);
+  return check_launch("symmetrize");
+}
+
+int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {
+  if (!W || !X || !dX) return fail(HECKA_EINVAL, "gram_bwd: null pointer%s");
+  if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "gram_bwd: bad size%s");
+  GemmOperands g;
+  g.A = W; g.B = X;
+  g.strideA = (long long)B * B;
+  g.strideB = (long long)B * P;
+  g.lda = B; g.ldb = P;
+  g.rowsA = B; g.colsB = P;
+  g.K = B; g.kchunk = B;
+  const bool vec = (B % 4 == 0) && (P % 4 == 0) && aligned16(W) && aligned16(X);
+  const int tilesM = (B + 127) / 128, tilesN = (P + 127) / 128;
+  dim3 grid(tilesM * tilesN, M);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(gram_bwd_kernel<true>, grid, dim3(kThreads), 0, st, g, dX, tilesN);
+  else
+    hipLaunchKernelGGL(gram_bwd_kernel<false>, grid, dim3(kThreads), 0, st, g, dX, tilesN);
+  return check_launch("gram_bwd");
+}
+
+}  // extern "C"

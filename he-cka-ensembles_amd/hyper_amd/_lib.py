@@ -1,0 +1,53 @@
+"""ctypes binding of libhecka.so (the C-ABI declared in include/hecka.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the
+product path raises.  Build it with `make -C he-cka-ensembles_amd/csrc` (or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhecka.so')
+_lib = None
+
+_vp, _i, _ll, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/hecka.h declares
+SIGNATURES = {
+    'hecka_version': (_i, []),
+    'hecka_last_error': (ctypes.c_char_p, []),
+    'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_center_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
+    'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
+    'hecka_coef_gamma_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_combine_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'hecka_rowmix_f32': (_i, [_vp, _vp, _i, _i, _ll, _vp, _vp]),
+    'hecka_center_rows_f32': (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
+    'hecka_symmetrize_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+
+def library_path():
+    return _PATH
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RuntimeError('libhecka.so not found at %s - build it with `make -C he-cka-ensembles_amd/csrc`; '
+                               'hyper_amd has no non-HIP fallback' % _PATH)
+        handle = ctypes.CDLL(_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().hecka_last_error()
+        raise RuntimeError('libhecka %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))

@@ -1,0 +1,218 @@
+"""Model kernels: the drop-in seam of the diversity loss.
+
+Same registry (`register_model_kernel` / `build_model_kernel`, YAML `name:` keys `feature`, `cka`,
+`he`, `model_layers`), ctor kwargs, forward signatures, `track` side effects and state-dict keys as
+the reference's hyper/diversity/model_kernels.py (registry :15-37, FeatureKernel :55-127,
+CKAModelKernel :208-256, HEModelKernel :259-414, ModelLayersKernel :417-491).
+
+What differs is underneath: for the linear feature kernel the per-layer chain
+    bmm -> detach_diagonal -> center_gram -> vector_norm/divide -> matmul
+(and its autograd backward) is ONE fused libhecka op, `ops.centered_gram_pairwise`, that writes the
+centred Gram once and returns the [M,M] matrix of Gram inner products; only [M,M]-sized arithmetic
+(normalise, arccos, energy, reduction, layer weights) stays in torch, which keeps gradients of
+learnable eps / arc_eps / layer weights for free.  `function` and `weight` kernels (SVGD methods)
+are outside the hot path and are not built."""
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import cos_from_inner, energy_from_cos, hyperspherical_energy, pairwise_cossim
+from .kernels import KERN_PARAMS, MAPS, batched_gram, center_gram
+from .layer_weighting import LayerWeighting, build_weighting  # noqa: F401
+
+AVAILABLE_KERNELS = {}
+
+
+def register_model_kernel(name):
+    def deco(cls):
+        AVAILABLE_KERNELS[name] = cls
+        return cls
+    return deco
+
+
+def build_model_kernel(config):
+    config = copy.deepcopy(config)
+    if 'name' not in config:
+        raise RuntimeError('model kernel config needs a `name` key')
+    cls = AVAILABLE_KERNELS[config.pop('name')]
+    return cls(**cls.from_config(config))
+
+
+class BaseModelKernel(nn.Module):
+    def forward(self, params, feats, pred, track, layer=None):
+        pass
+
+    @staticmethod
+    def from_config(config):
+        return config
+
+
+@register_model_kernel('feature')
+class FeatureKernel(BaseModelKernel):
+    """Batched Gram over tracked features [M,B,*].  `params` become fp32 0-dim Parameters under
+    `self.params.<name>` exactly as in the reference (state-dict compatible).  Unlike the reference
+    (model_kernels.py:78-80) the module-global default dict is NOT mutated: each instance starts from
+    a copy of the defaults."""
+
+    def __init__(self, kernel, detach_diag=False, readd_diag=True, params=None, learnable=False, *args, **kwargs):
+        super().__init__()
+        assert kernel in MAPS, 'Kernel {} not found. See kernels.py for available kernels'.format(kernel)
+        self.kernel = kernel
+        self.detach_diag = detach_diag
+        self.readd = readd_diag
+        self.args = args
+        self.kwargs = kwargs
+        self.dparams = dict(KERN_PARAMS.get(kernel, {}))
+        if params is not None:
+            self.dparams.update(params)
+        self.params = nn.ParameterDict(OrderedDict(
+            (k, nn.Parameter(torch.tensor(float(v)), requires_grad=learnable)) for k, v in self.dparams.items()))
+
+    @property
+    def fusable(self):
+        """True when the Gram -> centre -> pairwise chain can run as the single fused op."""
+        return self.kernel == 'linear' and (self.readd or not self.detach_diag) and not self.args and not self.kwargs
+
+    @staticmethod
+    def flatten(feats, flat_second=True):
+        if feats.ndim < (3 if flat_second else 2):
+            raise RuntimeError('Features must be have at least 2/3 dimensions (depending on flat second): '
+                               '(model bs, bs, dim1) or (model bs, bs). See model_kernels.py')
+        if flat_second:
+            return feats.reshape(feats.shape[0], feats.shape[1], -1)
+        return feats.reshape(feats.shape[0], -1).unsqueeze(0)
+
+    def batched_kernel(self, feats, flat_second=True, grad_vars=None):
+        X = self.flatten(feats, flat_second)
+        gram = batched_gram(X, None, self.kernel, self.detach_diag, self.readd, False, None, True,
+                            *self.args, **self.params, **self.kwargs)
+        if not flat_second:
+            gram = gram.squeeze(0)
+        if grad_vars is not None:
+            return gram, torch.autograd.grad(gram.sum(), grad_vars, retain_graph=True)[0]
+        return gram
+
+    def forward(self, params, feats, preds, track, layer=None):
+        return self.batched_kernel(feats)
+
+
+class _PairwiseHead(BaseModelKernel):
+    """Shared front of the CKA / HE kernels: features -> (cos matrix [M,M], centred Gram)."""
+
+    def _cosine(self, feats, eps, track):
+        fk = self.feature_kernel
+        if self.center and fk.fusable:
+            X = fk.flatten(feats)
+            S, nsq, gram = ops.centered_gram_pairwise(X, fk.detach_diag, self.detach_right)
+        else:
+            gram = fk.batched_kernel(feats)
+            if self.center:
+                gram = center_gram(gram)
+            S, nsq = ops.pairwise_inner_ad(gram.reshape(gram.shape[0], -1), self.detach_right)
+        track['gram'] = gram  # read by the `ckas` metric (hyper/experiments/metrics.py:75-91)
+        return cos_from_inner(S, nsq, eps, self.detach_right)
+
+    @staticmethod
+    def from_config(config):
+        config = BaseModelKernel.from_config(config)
+        config['feature_kernel'] = build_model_kernel(config['feature_kernel'])
+        return config
+
+
+@register_model_kernel('cka')
+class CKAModelKernel(_PairwiseHead):
+    def __init__(self, feature_kernel, eps=1e-6, center=True, reduction='off_diag', abs_vals=False,
+                 detach_right=False, learnable=False):
+        super().__init__()
+        self.feature_kernel = feature_kernel
+        self.center = center
+        self.abs_vals = abs_vals  # stored, never applied - as in the reference (:226, :231-249)
+        self.reduction = reduction
+        self.detach_right = detach_right
+        self.eps = nn.Parameter(torch.tensor(eps), requires_grad=learnable)
+
+    def forward(self, params, feats, preds, track, layer=None):
+        cos = self._cosine(feats, self.eps, track)
+        if self.reduction == 'off_diag':
+            return cos[~torch.eye(*cos.shape, dtype=torch.bool, device=cos.device)]
+        return cos
+
+
+@register_model_kernel('he')
+class HEModelKernel(_PairwiseHead):
+    def __init__(self, feature_kernel, he_s=2.0, eps=1e-6, arc_eps=1e-3, center=True, reduction='off_diag',
+                 abs_vals=False, detach_right=False, use_exp=False, normalize=False, learnable=False):
+        super().__init__()
+        if normalize:
+            raise NotImplementedError('normalize=True (min/max energy pre-solve) is enabled by no shipped config '
+                                      'and is not built')
+        self.feature_kernel = feature_kernel
+        self.center = center
+        self.abs_vals = abs_vals
+        self.reduction = reduction
+        self.detach_right = detach_right
+        self.he_s = he_s
+        self.eps = nn.Parameter(torch.tensor(eps), requires_grad=learnable)
+        self.arc_eps = nn.Parameter(torch.tensor(arc_eps), requires_grad=learnable)
+        self.use_exp = use_exp
+        self.normalize_he = normalize
+
+    def get_smoothing(self, detach=False, asfloat=False):
+        arc, eps = torch.abs(self.arc_eps), torch.abs(self.eps)
+        if detach:
+            arc, eps = arc.detach(), eps.detach()
+        if asfloat:
+            return arc.item(), eps.item()
+        return arc, eps
+
+    def forward(self, params, feats, preds, track, layer=None):
+        arc, eps = self.get_smoothing()
+        cos = self._cosine(feats, eps, track)
+        return energy_from_cos(cos, self.he_s, eps, arc, self.reduction == 'off_diag', self.abs_vals, self.use_exp)
+
+
+@register_model_kernel('model_layers')
+class ModelLayersKernel(BaseModelKernel):
+    """sum_l weight_l * reduce(layer_kernel_l(feats_l)); `track['layer_track'][l]['gram']` holds the
+    centred Gram of layer l."""
+
+    def __init__(self, layer_kernel, layer_weighting, reduction='mean'):
+        super().__init__()
+        self.different_kernels = isinstance(layer_kernel, list)
+        self.layer_kernel = nn.ModuleList(layer_kernel) if self.different_kernels else layer_kernel
+        self.layer_weighting = layer_weighting
+        self.reduction = reduction
+
+    def apply_reduction(self, model_grams):
+        if self.reduction == 'mean':
+            return model_grams.mean()
+        if self.reduction == 'sum':
+            return model_grams.sum()
+        return model_grams
+
+    def forward(self, params, feats, pred, track):
+        total = len(feats)
+        if total == 0:
+            return None
+        self.layer_weighting.reset_total()
+        self.layer_weighting.save_total(total)
+        layer_track = [OrderedDict() for _ in range(total)]
+        out = None
+        for index, feat in enumerate(feats.values()):
+            kern = self.layer_kernel[index] if self.different_kernels else self.layer_kernel
+            term = self.layer_weighting.get_weight(index, total) * self.apply_reduction(
+                kern(params, feat, pred, layer_track[index]))
+            out = term if out is None else out + term
+        track['layer_track'] = layer_track
+        return out
+
+    @staticmethod
+    def from_config(config):
+        config = BaseModelKernel.from_config(config)
+        lk = config['layer_kernel']
+        config['layer_kernel'] = [build_model_kernel(k) for k in lk] if isinstance(lk, list) else build_model_kernel(lk)
+        config['layer_weighting'] = build_weighting(config['layer_weighting'])
+        return config

@@ -1,0 +1,195 @@
+"""torch.autograd.Function wrappers around libhecka (raw device pointers + the current HIP stream).
+
+PyTorch is plumbing here: it owns the device memory and the stream; all arithmetic on [M,B,P]
+and [M,B,B] tensors happens in the HIP kernels."""
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_features(X):
+    if not X.is_cuda:
+        raise RuntimeError('hyper_amd kernels need features on the GPU (got %s); there is no CPU path' % X.device)
+    if X.dtype != torch.float32:
+        raise RuntimeError('hyper_amd kernels compute in fp32 (got %s)' % X.dtype)
+    if X.ndim != 3:
+        raise RuntimeError('expected features of shape [members, samples, features]')
+
+
+def centered_gram(X):
+    """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd."""
+    L = _lib.lib()
+    M, B, P = X.shape
+    sbar = torch.empty((M, P), device=X.device, dtype=torch.float32)
+    C = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+    cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    st = _stream()
+    _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), st), 'colmean')
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), M, B, P, _p(C), _p(cvec), st), 'gram_center')
+    return C, cvec
+
+
+def pairwise_inner(Ca, Cb=None):
+    """S[i,j] = <Ca[i], Cb[j]> over all trailing dims; no autograd."""
+    L = _lib.lib()
+    Cb = Ca if Cb is None else Cb
+    Ma, Mb = Ca.shape[0], Cb.shape[0]
+    K = Ca[0].numel()
+    S = torch.empty((Ma, Mb), device=Ca.device, dtype=torch.float32)
+    nbytes = L.hecka_pairwise_workspace_bytes(Ma, Mb, K)
+    ws = torch.empty((max(nbytes, 4) // 4,), device=Ca.device, dtype=torch.float32)
+    _lib.check(L.hecka_pairwise_f32(_p(Ca), Ma, _p(Cb), Mb, K, _p(S), _p(ws), nbytes, _stream()), 'pairwise')
+    return S
+
+
+def gram_backward(A, C, cvec, X, detach_diag):
+    """dX_i = (dC_i + dC_i^T, diag masked) X_i with dC_i = sum_j A[i,j] C[j]."""
+    L = _lib.lib()
+    Ma, Mb = A.shape
+    B, P = X.shape[1], X.shape[2]
+    st = _stream()
+    gamma = torch.empty((Ma, B), device=X.device, dtype=torch.float32)
+    W = torch.empty((Ma, B, B), device=X.device, dtype=torch.float32)
+    dX = torch.empty_like(X)
+    _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), st), 'coef_gamma')
+    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W), st), 'combine')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), Ma, B, P, _p(dX), st), 'gram_bwd')
+    return dX
+
+
+class CenteredGramPairwise(torch.autograd.Function):
+    """X [M,B,P] -> (S [M,M], nsq [M], C [M,B,B]).
+
+    C = centred linear Gram (the reference's track['gram']), S[i,j] = <C_i, C_j>, nsq = diag(S).
+    Gradients: dC_m = sum_j A_mj C_j with A = dS (+ dS^T unless `left_only`) + 2 diag(dnsq);
+    `left_only` gives S the gradient of C @ C.detach()^T (the reference's `detach_right`).
+    `detach_diag` zeroes the Gram diagonal's gradient (kernels.py:76-104).  C itself is returned
+    non-differentiable (it is a by-product for metrics)."""
+
+    @staticmethod
+    def forward(ctx, X, detach_diag, left_only):
+        _check_features(X)
+        X = X.contiguous()
+        C, cvec = centered_gram(X)
+        S = pairwise_inner(C)
+        nsq = torch.diagonal(S).clone()
+        ctx.save_for_backward(X, C, cvec)
+        ctx.detach_diag, ctx.left_only = bool(detach_diag), bool(left_only)
+        ctx.mark_non_differentiable(C)
+        return S, nsq, C
+
+    @staticmethod
+    def backward(ctx, dS, dnsq, _dC):
+        X, C, cvec = ctx.saved_tensors
+        M = X.shape[0]
+        A = torch.zeros((M, M), device=X.device, dtype=torch.float32)
+        if dS is not None:
+            A = A + (dS if ctx.left_only else dS + dS.t())
+        if dnsq is not None:
+            A = A + torch.diag_embed(2.0 * dnsq)
+        dX = gram_backward(A.contiguous(), C, cvec, X, ctx.detach_diag)
+        return dX, None, None
+
+
+def centered_gram_pairwise(X, detach_diag=True, left_only=False):
+    return CenteredGramPairwise.apply(X, detach_diag, left_only)
+
+
+class PairwiseInner(torch.autograd.Function):
+    """V [M,K] -> (S [M,M] = V V^T, nsq [M] = diag S) for arbitrary vectorised Grams.
+    backward: dV = (dS (+ dS^T unless left_only) + 2 diag(dnsq)) V   (one row-mix GEMM)."""
+
+    @staticmethod
+    def forward(ctx, V, left_only):
+        if not V.is_cuda or V.dtype != torch.float32:
+            raise RuntimeError('hyper_amd kernels need fp32 GPU tensors (got %s on %s)' % (V.dtype, V.device))
+        V = V.contiguous()
+        S = pairwise_inner(V)
+        ctx.save_for_backward(V)
+        ctx.left_only = bool(left_only)
+        return S, torch.diagonal(S).clone()
+
+    @staticmethod
+    def backward(ctx, dS, dnsq):
+        (V,) = ctx.saved_tensors
+        M, K = V.shape
+        A = torch.zeros((M, M), device=V.device, dtype=torch.float32)
+        if dS is not None:
+            A = A + (dS if ctx.left_only else dS + dS.t())
+        if dnsq is not None:
+            A = A + torch.diag_embed(2.0 * dnsq)
+        A = A.contiguous()
+        dV = torch.empty_like(V)
+        _lib.check(_lib.lib().hecka_rowmix_f32(_p(A), _p(V), M, M, K, _p(dV), _stream()), 'rowmix')
+        return dV, None
+
+
+def pairwise_inner_ad(V, left_only=False):
+    return PairwiseInner.apply(V, left_only)
+
+
+class LinearGram(torch.autograd.Function):
+    """X [M,B,P] -> K = X X^T (value of the diagonal kept; its gradient dropped when detach_diag).
+    backward: dX = (dK + dK^T, diag masked) X."""
+
+    @staticmethod
+    def forward(ctx, X, detach_diag):
+        _check_features(X)
+        X = X.contiguous()
+        L = _lib.lib()
+        M, B, P = X.shape
+        zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
+        K = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+        cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
+        _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), M, B, P, _p(K), _p(cvec), _stream()), 'gram')
+        ctx.save_for_backward(X)
+        ctx.detach_diag = bool(detach_diag)
+        return K
+
+    @staticmethod
+    def backward(ctx, dK):
+        (X,) = ctx.saved_tensors
+        L = _lib.lib()
+        M, B, P = X.shape
+        dK = dK.contiguous()
+        W = torch.empty_like(dK)
+        dX = torch.empty_like(X)
+        st = _stream()
+        _lib.check(L.hecka_symmetrize_f32(_p(dK), M, B, int(ctx.detach_diag), _p(W), st), 'symmetrize')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+        return dX, None
+
+
+def linear_gram(X, detach_diag=True):
+    return LinearGram.apply(X, detach_diag)
+
+
+class CenterRows(torch.autograd.Function):
+    """gram - rowmean(gram) over the last dim; self-adjoint, so backward is the same kernel."""
+
+    @staticmethod
+    def forward(ctx, G):
+        if not G.is_cuda or G.dtype != torch.float32:
+            raise RuntimeError('hyper_amd kernels need fp32 GPU tensors (got %s on %s)' % (G.dtype, G.device))
+        G = G.contiguous()
+        out = torch.empty_like(G)
+        cols = G.shape[-1]
+        _lib.check(_lib.lib().hecka_center_rows_f32(_p(G), G.numel() // cols, cols, _p(out), None, _stream()),
+                   'center_rows')
+        return out
+
+    @staticmethod
+    def backward(ctx, dC):
+        return CenterRows.apply(dC)
+
+
+def center_rows(G):
+    return CenterRows.apply(G)

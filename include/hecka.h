@@ -1,0 +1,91 @@
+/* libhecka — C-ABI of the MI355X (gfx950) HE-CKA diversity-loss hot path.
+ *
+ * The reference (Deep-Machine-Vision/he-cka-ensembles) is pure Python/PyTorch and has no FFI
+ * for this path; each entry point below names the reference Python function
+ * (file:line under /root/reference) whose device work it replaces.  The host-side mirror of the
+ * reference plugin API (`hyper_amd.diversity.*`) binds these with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - all tensors are fp32, row-major, contiguous; M = members, B = samples, P = features;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); work is enqueued,
+ *     never synchronised; no entry point allocates, frees or copies to the host;
+ *   - return value: 0 = ok, <0 = error (HECKA_E*); hecka_last_error() gives the message of the
+ *     calling thread's last failure.  Nothing throws.
+ */
+#ifndef HECKA_H
+#define HECKA_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HECKA_OK 0
+#define HECKA_EINVAL (-1)    /* bad argument (null pointer, non-positive size, misuse) */
+#define HECKA_ELAUNCH (-2)   /* HIP reported a launch error */
+#define HECKA_EWORKSPACE (-3) /* workspace too small */
+
+int hecka_version(void);
+const char* hecka_last_error(void);
+
+/* Column mean of each member's features: sbar[m,p] = (1/B) sum_b X[m,b,p].
+ * First half of the fused replacement of center_gram (hyper/diversity/kernels.py:335-345):
+ * C = K - rowmean(K) == X (X - 1 sbar^T)^T, so the centring is applied to the features. */
+int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream);
+
+/* Centred linear Gram of every member, written once:
+ *   C[m] = X_m X_m^T - rowmean(X_m X_m^T)   ([M,B,B]),   cvec[m,b] = sbar_m . (x_b - sbar_m)  ([M,B])
+ * computed as Kt = (X-1 sbar^T)(X-1 sbar^T)^T on fp32 MFMA (upper-triangular tiles, mirrored) and
+ * C = Kt + 1 cvec^T.  Replaces linear_gram + detach_diagonal(forward value) + center_gram
+ * (hyper/diversity/kernels.py:107-127, 76-104, 335-345) as called from FeatureKernel.batched_kernel
+ * (hyper/diversity/model_kernels.py:84-123) and HEModelKernel.forward (:369-377). */
+int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P,
+                          float* C, float* cvec, void* stream);
+
+/* Pairwise inner products of vectorised Grams: S[i,j] = <Ca[i,:], Cb[j,:]>, Ca [Ma,K], Cb [Mb,K],
+ * K = B*B.  Split-K over workgroups with a fixed-order (deterministic) second-stage sum.
+ * Replaces vectorize_grams + the matmul of unit_vector_rows outputs (the norms are the diagonal
+ * of S) in pairwise_cossim / hyperspherical_energy (hyper/diversity/__init__.py:33-56, 79-108).
+ * Ca == Cb, Ma == Mb on one GPU; with members sharded over GPUs Ca holds the local members and
+ * Cb the all-gathered ones.  `ws` needs hecka_pairwise_workspace_bytes(Ma, Mb, K) bytes. */
+size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K);
+int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K,
+                       float* S, void* ws, size_t ws_bytes, void* stream);
+
+/* gamma[i,b] = sum_j A[i,j] cvec[j,b]   (A [Ma,Mb], cvec [Mb,B], gamma [Ma,B]). */
+int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int B,
+                         float* gamma, void* stream);
+
+/* Gradient w.r.t. the (uncentred) Gram, symmetrised for the feature GEMM:
+ *   dC_i = sum_j A[i,j] C_j ;   W_i = dC_i + dC_i^T = 2 dC_i + gamma_i 1^T - 1 gamma_i^T ;
+ *   diag(W_i) = 0 when detach_diag.
+ * A [Ma,Mb] is dLoss/dS symmetrised by the caller, C [Mb,B,B], gamma [Ma,B], W [Ma,B,B].
+ * Replaces autograd's backward of matmul/normalise/center_gram/detach_diagonal
+ * (ParticleMethods.backward, hyper/diversity/methods.py:139-152). */
+int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B,
+                      int detach_diag, float* W, void* stream);
+
+/* out = A V   (A [Ma,Mb], V [Mb,K], out [Ma,K]) — backward of the generic pairwise inner product
+ * (autograd of the matmul in hyper/diversity/__init__.py:47,108 for Grams that did not come from
+ * hecka_gram_center_f32). */
+int hecka_rowmix_f32(const float* A, const float* V, int Ma, int Mb, long long K, float* out, void* stream);
+
+/* Row centring of a [rows, cols] matrix: out = V - rowmean(V) (out may be NULL), mean[r] = rowmean
+ * (mean may be NULL).  center_gram (hyper/diversity/kernels.py:335-345) and, being self-adjoint, its
+ * own backward. */
+int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, float* mean, void* stream);
+
+/* W[m] = G[m] + G[m]^T, diagonal zeroed when detach_diag — turns dLoss/dK into the symmetric factor
+ * of dX = W X; backward of torch.bmm(X, X^T) + detach_diagonal (hyper/diversity/kernels.py:122-125, 76-104). */
+int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W, void* stream);
+
+/* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
+ * (hyper/diversity/kernels.py:122) on fp32 MFMA. */
+int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HECKA_H */

@@ -1,0 +1,147 @@
+"""GPU parity: the HIP path (through the C-ABI, via hyper_amd) against the golden vectors of the real
+reference and against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): rel 1e-5 in fp32 for loss and gradients.  Gradients are compared
+relative to the largest gradient magnitude of the layer (max-norm relative error)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def _built(name):
+    import json
+    rec = load_golden(name, 'f64')
+    return rec['config']['layer_kernel']['feature_kernel']['kernel'] == 'linear'
+
+
+LINEAR = [n for n in golden_cases('f64') if _built(n)]
+
+
+def _relerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize('name', LINEAR)
+def test_model_kernel_matches_reference_golden(name):
+    """hyper_amd.build_model_kernel(cfg)(feats) on the GPU vs the reference's own fp64 output."""
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from collections import OrderedDict
+    rec = load_golden(name, 'f64')
+    dev = _dev()
+    kern = build_model_kernel(rec['config']).to(dev)
+    xs = [torch.from_numpy(rec['x%d' % i]).float().to(dev).requires_grad_(True) for i in range(rec['L'])]
+    # golden inputs are fp64; the GPU path sees their fp32 rounding, so compare against the oracle run
+    # on exactly those rounded inputs in fp64 (and, loosely, against the golden fp64 outputs)
+    from oracle import hecka_ref as R
+    xo = [x.detach().cpu().double().requires_grad_(True) for x in xs]
+    ref = R.run_config(rec['config'], xo)
+    track = OrderedDict()
+    out = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
+    if out.ndim == 0:
+        out.backward()
+        ref.backward()
+    else:
+        up = torch.from_numpy(rec['upstream'])
+        (out * up.float().to(dev)).sum().backward()
+        (ref * up).sum().backward()
+    # the diagonal pair (i,i) of reduction='none' is ill-conditioned in fp32 (see test_oracle_golden)
+    tol = 5e-3 if name == 'he_lin_none' else RTOL
+    assert _relerr(out.detach().cpu().numpy(), ref.detach().numpy()) <= tol
+    assert _relerr(out.detach().cpu().numpy(), rec['out']) <= max(tol, 1e-4)
+    for i, x in enumerate(xs):
+        assert _relerr(x.grad.cpu().numpy(), xo[i].grad.numpy()) <= (2e-2 if name == 'he_lin_none' else RTOL), 'layer %d' % i
+        if 'gram%d' % i in rec:
+            g = track['layer_track'][i]['gram'].cpu().numpy()
+            assert _relerr(g, rec['gram%d' % i]) <= 1e-4
+
+
+@pytest.mark.parametrize('M,B,P', [(3, 37, 19), (5, 300, 84), (2, 130, 10), (4, 128, 256), (2, 257, 515), (1, 8, 4)])
+def test_kernels_ragged_shapes(M, B, P):
+    """Each C-ABI entry point at ragged / unaligned sizes against fp64 torch on the CPU."""
+    from hyper_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 1000 + B + P)
+    X = (torch.randn(M, B, P, generator=g) + 0.5).to(dev)
+    Xd = X.cpu().double()
+    C, cvec = ops.centered_gram(X)
+    K = Xd @ Xd.transpose(1, 2)
+    Cref = K - K.mean(2, keepdim=True)
+    assert _relerr(C.cpu().numpy(), Cref.numpy()) <= 2e-6
+    S = ops.pairwise_inner(C)
+    Cf = Cref.reshape(M, -1)
+    assert _relerr(S.cpu().numpy(), (Cf @ Cf.t()).numpy()) <= 5e-6
+    A = torch.randn(M, M, generator=g).to(dev)
+    dX = ops.gram_backward(A, C, cvec, X, True)
+    dC = torch.einsum('ij,jab->iab', A.cpu().double(), Cref)
+    W = (dC + dC.transpose(1, 2)) * (1 - torch.eye(B, dtype=torch.float64))
+    assert _relerr(dX.cpu().numpy(), (W @ Xd).numpy()) <= 1e-5
+    # un-fused functional pieces
+    Kg = ops.linear_gram(X.clone().requires_grad_(True), True)
+    assert _relerr(Kg.detach().cpu().numpy(), K.numpy()) <= 2e-6
+    Cc = ops.center_rows(Kg.detach())
+    assert _relerr(Cc.cpu().numpy(), Cref.numpy()) <= 1e-5
+
+
+def test_unfused_api_matches_fused():
+    """batched_gram + hyperspherical_energy (un-fused functional API) == fused model kernel."""
+    from hyper_amd.diversity import hyperspherical_energy
+    from hyper_amd.diversity.kernels import batched_gram
+    from hyper_amd import ops
+    from hyper_amd.diversity import cos_from_inner, energy_from_cos
+    dev = _dev()
+    torch.manual_seed(5)
+    X = torch.randn(6, 48, 40, device=dev)
+    xa = X.clone().requires_grad_(True)
+    e1 = hyperspherical_energy(batched_gram(xa, None, kernel='linear', detach_diag=True, center=True),
+                               s=2.0, eps=0.0025, arc_eps=0.031).mean()
+    e1.backward()
+    xb = X.clone().requires_grad_(True)
+    S, nsq, _ = ops.centered_gram_pairwise(xb, True, False)
+    e2 = energy_from_cos(cos_from_inner(S, nsq, 0.0025), 2.0, 0.0025, 0.031).mean()
+    e2.backward()
+    assert abs(e1.item() - e2.item()) <= 1e-5 * abs(e2.item())
+    assert _relerr(xa.grad.cpu().numpy(), xb.grad.cpu().double().numpy()) <= 2e-5
+
+
+def test_bench_shape_properties():
+    """Full bench sizes (M=64, B=512): size-independent properties instead of an oracle run:
+    rows of C sum to zero, diag(S) = |C_m|^2, S symmetric, loss/grad scale linearity,
+    and dX against a directional finite difference of the loss computed by the same HIP forward."""
+    from hyper_amd import ops
+    from hyper_amd.diversity import cos_from_inner, energy_from_cos
+    dev = _dev()
+    torch.manual_seed(1234)
+    M, B, P = 64, 512, 512
+    X = torch.randn(M, B, P, device=dev)
+    C, cvec = ops.centered_gram(X)
+    assert float(C.sum(2).abs().max()) <= 1e-3 * float(C.abs().max())
+    S = ops.pairwise_inner(C)
+    nsq = (C.double() ** 2).sum((1, 2))
+    assert _relerr(torch.diagonal(S).cpu().numpy(), nsq.cpu().numpy()) <= 1e-5
+    assert float((S - S.t()).abs().max()) <= 1e-5 * float(S.abs().max())
+
+    def loss_of(x):
+        s, n, _ = ops.centered_gram_pairwise(x, True, False)
+        return energy_from_cos(cos_from_inner(s, n, 0.0025), 2.0, 0.0025, 0.031).mean()
+
+    x = X.clone().requires_grad_(True)
+    loss = loss_of(x)
+    loss.backward()
+    d = torch.randn_like(X)
+    d = d / d.norm()
+    h = 0.5
+    with torch.no_grad():
+        fd = (loss_of(X + h * d).double() - loss_of(X - h * d).double()) / (2 * h)
+    an = (x.grad.double() * d.double()).sum()
+    assert abs(fd.item() - an.item()) <= 2e-2 * abs(an.item()) + 1e-9
