@@ -1,0 +1,144 @@
+"""HE-CKA loss+grad microbenchmark (BASELINE.json configs[3]: M=64 members, B=512 samples, 5 tracked layers
+with feature dims 512..8192, fp32, synthetic features).
+
+One "step" = one eval = scalar `model_layers` HE loss AND dLoss/dX for all five layers, through the
+drop-in `hyper_amd` model kernel (autograd.Function -> ctypes -> libhecka HIP kernels).  Inputs are
+resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+M, B = 64, 512
+DIMS = [512, 1024, 2048, 4096, 8192]
+CFG = {'name': 'model_layers',
+       'layer_kernel': {'name': 'he', 'he_s': 2.0, 'eps': 0.0025, 'arc_eps': 0.031,
+                        'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}},
+       'layer_weighting': {'name': 'uniform'}}
+PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def make_feats(dev, members):
+    torch.manual_seed(1234)
+    feats = []
+    for p in DIMS:
+        x = torch.randn(M, B, p)          # same global tensor on every rank, then the rank's member slice
+        feats.append(x[members].contiguous().to(dev))
+    return feats
+
+
+def cpu_baseline():
+    """The oracle (reference op sequence, stock PyTorch autograd) on this box's host cores,
+    one full eval of the same workload."""
+    from oracle import hecka_ref as R
+    torch.manual_seed(1234)
+    feats = [torch.randn(M, B, p) for p in DIMS]
+    lk = CFG['layer_kernel']
+    cfg = dict(kernel='linear', detach_diag=True, he_s=lk['he_s'], eps=lk['eps'], arc_eps=lk['arc_eps'])
+    w = R.layer_weights('uniform', len(DIMS))
+    t0 = time.perf_counter()
+    R.loss_and_grads(feats, cfg, w)
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / dt, 'unit': 'evals/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 full eval (M=64,B=512,P=512..8192 x5 layers, fp32, torch %s CPU autograd), %.1f s' % (torch.__version__, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from hyper_amd import ops
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+
+    if world > 1:
+        raise NotImplementedError('member-sharded multi-GPU path lands in hyper_amd.parallel (next step)')
+    members = slice(0, M)
+    feats = make_feats(dev, members)
+    kern = build_model_kernel(CFG).to(dev)
+    xs = [f.requires_grad_(True) for f in feats]
+    fdict = OrderedDict((str(i), x) for i, x in enumerate(xs))
+
+    def step():
+        for x in xs:
+            x.grad = None
+        loss = kern(None, fdict, None, OrderedDict())
+        loss.backward()
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILE = {'gram_bwd': []}       # HIP events around the dominant kernel, on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        # dominant kernel: dX = W X (gram_bwd_kernel), 2*M*B*B*P flop per launch (SURVEY.md 8d per-unit figure)
+        kms = sum(a.elapsed_time(b) for a, b, _ in prof['gram_bwd'])
+        kfl = sum(fl for _, _, fl in prof['gram_bwd'])
+        ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        flops_eval = sum(4.0 * M * B * B * p + 4.0 * M * M * B * B for p in DIMS)
+        out = {
+            'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
+                                   'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
+                       'loss': float(loss.item()), 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},
+            'roofline': {'bound': 'mfma', 'kernel': 'gram_bwd_kernel (dX = W X, fp32 MFMA)', 'achieved': ach,
+                         'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MATRIX_TFLOPS,
+                         'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': None},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

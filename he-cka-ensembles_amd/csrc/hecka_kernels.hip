@@ -20,6 +20,9 @@ static int check_launch(const char* what) {
   if (e != hipSuccess) return fail(HECKA_ELAUNCH, "%s: launch failed (%lld)", what, (long long)e);
   return HECKA_OK;
 }
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated runtime call left behind so
+// that check_launch reports only this launch.
+static inline void clear_error() { (void)hipGetLastError(); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ------------------------------------------------------------------------------------------
@@ -309,6 +312,7 @@ int hecka_version(void) { return 1; }
 const char* hecka_last_error(void) { return g_err; }
 
 int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream) {
+  clear_error();
   if (!X || !sbar) return fail(HECKA_EINVAL, "colmean: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "colmean: non-positive size%s");
   if (M > 65535) return fail(HECKA_EINVAL, "colmean: M > 65535%s");
@@ -324,6 +328,7 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* st
 
 int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P, float* C, float* cvec,
                           void* stream) {
+  clear_error();
   if (!X || !sbar || !C || !cvec) return fail(HECKA_EINVAL, "gram_center: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_center: non-positive size%s");
   if (M > 65535) return fail(HECKA_EINVAL, "gram_center: M > 65535%s");
@@ -352,6 +357,7 @@ size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {
 
 int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* ws,
                        size_t ws_bytes, void* stream) {
+  clear_error();
   if (!Ca || !Cb || !S || !ws) return fail(HECKA_EINVAL, "pairwise: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise: non-positive size%s");
   if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "pairwise: K too large (%lld)%s", "", K);
@@ -383,6 +389,7 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
 }
 
 int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int B, float* gamma, void* stream) {
+  clear_error();
   if (!A || !cvec || !gamma) return fail(HECKA_EINVAL, "coef_gamma: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || B <= 0 || Ma > 65535) return fail(HECKA_EINVAL, "coef_gamma: bad size%s");
   hipLaunchKernelGGL(coef_gamma_kernel, dim3((B + 255) / 256, Ma), dim3(256), 0, (hipStream_t)stream, A, cvec, Ma, Mb,
@@ -392,6 +399,7 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
 
 static int combine_impl(const float* A, const float* C, const float* gamma, int Ma, int Mb, long long N, int B,
                         int detach_diag, float* W, void* stream, int mode) {
+  clear_error();
   if (!A || !C || !W || (mode == 1 && !gamma)) return fail(HECKA_EINVAL, "combine: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || N <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
   if (N > 0x7fffffffLL - 128) return fail(HECKA_EINVAL, "combine: row length too large%s");
@@ -430,6 +438,7 @@ int hecka_rowmix_f32(const float* A, const float* V, int Ma, int Mb, long long K
 }
 
 int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, float* mean, void* stream) {
+  clear_error();
   if (!V || (!out && !mean)) return fail(HECKA_EINVAL, "center_rows: null pointer%s");
   if (rows <= 0 || cols <= 0 || rows > 0x7fffffffLL) return fail(HECKA_EINVAL, "center_rows: bad size%s");
   hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, V, cols, out, mean);
@@ -437,6 +446,7 @@ int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, 
 }
 
 int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W, void* stream) {
+  clear_error();
   if (!G || !W) return fail(HECKA_EINVAL, "symmetrize: null pointer%s");
   if (M <= 0 || B <= 0 || M > 65535) return fail(HECKA_EINVAL, "symmetrize: bad size%s");
   if (G == W) return fail(HECKA_EINVAL, "symmetrize: in-place not supported%s");
@@ -446,6 +456,7 @@ int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {
+  clear_error();
   if (!W || !X || !dX) return fail(HECKA_EINVAL, "gram_bwd: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "gram_bwd: bad size%s");
   GemmOperands g;

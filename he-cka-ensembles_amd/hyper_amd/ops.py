@@ -7,6 +7,11 @@ import torch
 from . import _lib
 
 
+# bench.py sets this to {'gram_bwd': []} to collect (start_event, end_event, flops) around the dominant
+# kernel's launches on the launch stream; None in normal operation.
+PROFILE = None
+
+
 def _p(t):
     return t.data_ptr()
 
@@ -61,7 +66,13 @@ def gram_backward(A, C, cvec, X, detach_diag):
     dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), st), 'coef_gamma')
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W), st), 'combine')
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), Ma, B, P, _p(dX), st), 'gram_bwd')
+    if PROFILE is not None:
+        e1.record()
+        PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
     return dX
 
 

@@ -62,7 +62,7 @@ def rbf_gram(X, param=1.0, median=True, detach_diag=True, readd=True):
             w = 2.0 * math.log(X.shape[1] + 1)
             h = torch.stack([float(param) * d[m].median() / w for m in range(M)]).view(M, 1, 1)
     else:
-        h = torch.full((M, 1, 1), float(param) ** 2, dtype=X.dtype)
+        h = torch.full((M, 1, 1), float(param) ** 2, dtype=X.dtype, device=X.device)
     return torch.exp(-d / (2.0 * h))
 
 
@@ -93,7 +93,7 @@ def unit_vector_rows(grams, eps):
 
 
 def _offdiag(mat):
-    return mat[~torch.eye(*mat.shape, dtype=torch.bool)]
+    return mat[~torch.eye(*mat.shape, dtype=torch.bool, device=mat.device)]
 
 
 def pairwise_cossim(grams, eps=1e-6, reduction='off_diag', detach_right=False):
