@@ -100,15 +100,14 @@ struct GemmTile {
         const int idx = t + kThreads * i;
         const int r = idx >> 3, c4 = idx & 7;
         ra[i] = load_row4<VEC>(Ab, g.lda, row0 + r, g.rowsA, k0 + 4 * c4, kend);
-        pro.stageA(ra[i], i, row0 + r, k0 + 4 * c4, kend);
       }
+      pro.prefetch(k0 + 4 * (t & 7), kend);  // every float4 this thread stages sits in k-column (t & 7)
       if (!NN) {
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
           const int idx = t + kThreads * i;
           const int r = idx >> 3, c4 = idx & 7;
           rb[i] = load_row4<VEC>(Bb, g.ldb, col0 + r, g.colsB, k0 + 4 * c4, kend);
-          pro.stageB(rb[i], i, col0 + r, k0 + 4 * c4, kend);
         }
       } else {
 #pragma unroll
@@ -132,15 +131,19 @@ struct GemmTile {
         }
       }
     };
+    // The prologue transform is applied HERE (after the MFMAs of the previous tile), never in gload:
+    // touching a freshly loaded register there would put the global-load latency in front of the MFMAs.
     auto lstore = [&](int buf) {
 #pragma unroll
       for (int i = 0; i < A4; ++i) {
         const int idx = t + kThreads * i;
+        pro.stageA(ra[i], i, row0 + (idx >> 3));
         *reinterpret_cast<f32x4*>(&sm.a[buf][(idx >> 3) * kLDK + 4 * (idx & 7)]) = ra[i];
       }
 #pragma unroll
       for (int i = 0; i < B4; ++i) {
         const int idx = t + kThreads * i;
+        if (!NN) pro.stageB(rb[i], i, col0 + (idx >> 3));
         if (!NN)
           *reinterpret_cast<f32x4*>(&sm.b[buf][(idx >> 3) * kLDK + 4 * (idx & 7)]) = rb[i];
         else
@@ -208,8 +211,9 @@ struct GemmTile {
 };
 
 struct NoPrologue {
-  __device__ __forceinline__ void stageA(f32x4&, int, int, int, int) {}
-  __device__ __forceinline__ void stageB(f32x4&, int, int, int, int) {}
+  __device__ __forceinline__ void prefetch(int, int) {}
+  __device__ __forceinline__ void stageA(f32x4&, int, int) {}
+  __device__ __forceinline__ void stageB(f32x4&, int, int) {}
 };
 
 }  // namespace hecka

@@ -69,8 +69,9 @@ template <int TM, bool VEC>
 struct CenterPro {
   const float* sbar;  // this member's column means [P]
   int rows;           // B
+  f32x4 s4;           // means of the k-column this thread stages in the tile in flight
   float ca[TM / 32], cb[TM / 32];
-  __device__ __forceinline__ f32x4 mean4(int k, int kend) const {
+  __device__ __forceinline__ void prefetch(int k, int kend) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
       if (k < kend) s = *reinterpret_cast<const f32x4*>(sbar + k);
@@ -79,20 +80,18 @@ struct CenterPro {
       for (int e = 0; e < 4; ++e)
         if (k + e < kend) s[e] = sbar[k + e];
     }
-    return s;
+    s4 = s;
   }
-  __device__ __forceinline__ void stageA(f32x4& v, int i, int row, int k, int kend) {
+  __device__ __forceinline__ void stageA(f32x4& v, int i, int row) {
     if (row < rows) {
-      const f32x4 s = mean4(k, kend);
-      v -= s;
-      ca[i] += v[0] * s[0] + v[1] * s[1] + v[2] * s[2] + v[3] * s[3];
+      v -= s4;
+      ca[i] += v[0] * s4[0] + v[1] * s4[1] + v[2] * s4[2] + v[3] * s4[3];
     }
   }
-  __device__ __forceinline__ void stageB(f32x4& v, int i, int row, int k, int kend) {
+  __device__ __forceinline__ void stageB(f32x4& v, int i, int row) {
     if (row < rows) {
-      const f32x4 s = mean4(k, kend);
-      v -= s;
-      cb[i] += v[0] * s[0] + v[1] * s[1] + v[2] * s[2] + v[3] * s[3];
+      v -= s4;
+      cb[i] += v[0] * s4[0] + v[1] * s4[1] + v[2] * s4[2] + v[3] * s4[3];
     }
   }
 };
@@ -178,12 +177,24 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
   });
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int n, float* __restrict__ S) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Fixed-order second stage: block = 16 outputs x 16 z-lanes; lane zl sums z = zl, zl+16, ... and the 16
+// lane sums are added in lane order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int n,
+                                                            float* __restrict__ S) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + o;
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += part[(size_t)z * n + i];
-  S[i] = s;
+  if (i < n)
+    for (int z = zl; z < nsplit; z += 16) s += part[(size_t)z * n + i];
+  red[zl][o] = s;
+  __syncthreads();
+  if (zl == 0 && i < n) {
+    float tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot += red[r][o];
+    S[i] = tot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,7 +395,7 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   int rc = check_launch("pairwise");
   if (rc) return rc;
   const int n = Ma * Mb;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, nsplit, n, S);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, nsplit, n, S);
   return check_launch("pairwise_reduce");
 }
 

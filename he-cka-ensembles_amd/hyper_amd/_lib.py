@@ -39,6 +39,9 @@ def lib():
         if not os.path.exists(_PATH):
             raise RuntimeError('libhecka.so not found at %s - build it with `make -C he-cka-ensembles_amd/csrc`; '
                                'hyper_amd has no non-HIP fallback' % _PATH)
+        # torch bundles its own libamdhip64; load it first so libhecka binds to the SAME HIP runtime
+        # (two runtimes in one process do not share devices or allocations)
+        import torch  # noqa: F401
         handle = ctypes.CDLL(_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
