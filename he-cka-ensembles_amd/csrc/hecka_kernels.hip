@@ -303,6 +303,127 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// (8) pairwise head on the [Ma,Mb] matrix of Gram inner products (tiny; one workgroup, fp64 inside):
+//       cos_ij = S_ij / ((n_i+eps)(n_j+eps)),  HE: theta = arccos(|cos| / (1+arc_eps)), energy branch
+//     fwd: value matrix + optional scaled sum;  bwd: coefficient matrix A with dC_i = sum_j A_ij C_j.
+// ------------------------------------------------------------------------------------------
+struct HeadCfg {
+  int kind;          // 0 = cka (value = cos), 1 = he (value = energy(theta))
+  int use_exp, abs_vals, remove_diag, detach_right;
+  int row_offset;    // global member index of local row 0 (members sharded over GPUs)
+  double s, eps, arc_eps;
+};
+
+__device__ __forceinline__ void head_value(const HeadCfg& c, double cosv, double& val, double& dval_dcos) {
+  if (c.kind == 0) {
+    val = cosv;
+    dval_dcos = 1.0;
+    return;
+  }
+  const double a = c.abs_vals ? fabs(cosv) : cosv;
+  const double z = a / (1.0 + c.arc_eps);
+  const double th = acos(z);
+  double e, de;  // energy and d energy / d theta
+  if (c.s == 0.0) {
+    const double inv = 1.0 / (th + c.eps);
+    e = log(inv + c.eps);
+    de = (-inv * inv) / (inv + c.eps);
+  } else if (c.s == 1.0) {
+    const double inv = 1.0 / (th + c.eps);
+    e = inv;
+    de = -inv * inv;
+  } else if (c.use_exp) {
+    e = exp(-(c.s * th + c.eps));
+    de = -c.s * e;
+  } else {
+    const double den = pow(th, c.s) + c.eps;
+    e = (1.0 + c.eps) / den;
+    de = -(1.0 + c.eps) * c.s * pow(th, c.s - 1.0) / (den * den);
+  }
+  val = e;
+  double d = de * (-1.0 / sqrt(1.0 - z * z)) / (1.0 + c.arc_eps);
+  if (c.abs_vals && cosv < 0.0) d = -d;
+  dval_dcos = d;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                       int Ma, int Mb, HeadCfg c, float* __restrict__ val,
+                                                       float* __restrict__ sum_out, double scale) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < Ma * Mb; e += 256) {
+    const int i = e / Mb, j = e - i * Mb;
+    const double di = sqrt((double)nsq[c.row_offset + i]) + c.eps, dj = sqrt((double)nsq[j]) + c.eps;
+    double v, dv;
+    head_value(c, (double)S[e] / (di * dj), v, dv);
+    if (val) val[e] = (float)v;
+    if (!(c.remove_diag && j == c.row_offset + i)) acc += v;
+  }
+  const double tot = block_sum_256(acc, red);
+  if (sum_out && threadIdx.x == 0) *sum_out = (float)(tot * scale);
+}
+
+// upstream dLoss/dvalue_ij = (up_mat ? up_mat[i,j] : 1) * (up_scalar ? *up_scalar : 1) * scale.
+// A matrix upstream needs the transposed entry too, so it requires Ma == Mb (single GPU).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                       int Ma, int Mb, HeadCfg c, const float* __restrict__ up_mat,
+                                                       const float* __restrict__ up_scalar, double scale,
+                                                       float* __restrict__ A) {
+  const double us = (up_scalar ? (double)*up_scalar : 1.0) * scale;
+  // phase 1: Gs_ij = G_ij (+ G_ji)   (cos is symmetric, so G_ji differs from G_ij only through up_mat)
+  for (int e = threadIdx.x; e < Ma * Mb; e += 256) {
+    const int i = e / Mb, j = e - i * Mb;
+    const int gi = c.row_offset + i;
+    double g = 0.0;
+    if (!(c.remove_diag && j == gi)) {
+      const double di = sqrt((double)nsq[gi]) + c.eps, dj = sqrt((double)nsq[j]) + c.eps;
+      double v, dv;
+      head_value(c, (double)S[e] / (di * dj), v, dv);
+      const double uij = (up_mat ? (double)up_mat[e] : 1.0) * us;
+      g = uij * dv;
+      if (!c.detach_right) {
+        const double uji = (up_mat ? (double)up_mat[(size_t)j * Mb + gi] : 1.0) * us;
+        g += uji * dv;
+      }
+    }
+    A[e] = (float)g;
+  }
+  __syncthreads();
+  // phase 2: one wave per row: A_ij = Gs_ij/(d_i d_j);  A_ii = Gs_ii eps/d_i^3 - (sum_{j!=i} Gs_ij S_ij/d_j)/(n_i d_i^2)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < Ma; i += 4) {
+    const int gi = c.row_offset + i;
+    const double ni = sqrt((double)nsq[gi]), di = ni + c.eps;
+    double vg = 0.0;
+    for (int j = lane; j < Mb; j += 64) {
+      const double dj = sqrt((double)nsq[j]) + c.eps;
+      const double g = (double)A[(size_t)i * Mb + j];
+      if (j != gi) {
+        vg += g * (double)S[(size_t)i * Mb + j] / dj;
+        A[(size_t)i * Mb + j] = (float)(g / (di * dj));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vg += __shfl_xor(vg, o);
+    if (lane == 0) {
+      const double gii = (double)A[(size_t)i * Mb + gi];
+      const double self = ni > 0.0 ? vg / (ni * di * di) : 0.0;
+      A[(size_t)i * Mb + gi] = (float)(gii * c.eps / (di * di * di) - self);
+    }
+  }
+}
+
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -464,6 +585,43 @@ int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W
   const int nt = (B + 31) / 32;
   hipLaunchKernelGGL(symmetrize_kernel, dim3(nt, nt, M), dim3(256), 0, (hipStream_t)stream, G, B, detach_diag, W);
   return check_launch("symmetrize");
+}
+
+static int head_cfg(HeadCfg& c, int kind, double s, double eps, double arc_eps, int flags, int row_offset, int Ma,
+                    int Mb) {
+  if (Ma <= 0 || Mb <= 0 || row_offset < 0 || row_offset + Ma > Mb) return fail(HECKA_EINVAL, "head: bad sizes%s");
+  if (kind != 0 && kind != 1) return fail(HECKA_EINVAL, "head: kind must be 0 (cka) or 1 (he)%s");
+  c.kind = kind;
+  c.use_exp = (flags & HECKA_HEAD_USE_EXP) != 0;
+  c.abs_vals = (flags & HECKA_HEAD_ABS_VALS) != 0;
+  c.remove_diag = (flags & HECKA_HEAD_REMOVE_DIAG) != 0;
+  c.detach_right = (flags & HECKA_HEAD_DETACH_RIGHT) != 0;
+  c.row_offset = row_offset;
+  c.s = s; c.eps = eps; c.arc_eps = arc_eps;
+  return HECKA_OK;
+}
+
+int hecka_head_fwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row_offset, int kind, double s, double eps,
+                       double arc_eps, int flags, float* val, float* sum_out, double scale, void* stream) {
+  clear_error();
+  if (!S || !nsq || (!val && !sum_out)) return fail(HECKA_EINVAL, "head_fwd: null pointer%s");
+  HeadCfg c;
+  if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
+  return check_launch("head_fwd");
+}
+
+int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row_offset, int kind, double s, double eps,
+                       double arc_eps, int flags, const float* up_mat, const float* up_scalar, double scale, float* A,
+                       void* stream) {
+  clear_error();
+  if (!S || !nsq || !A) return fail(HECKA_EINVAL, "head_bwd: null pointer%s");
+  if (up_mat && Ma != Mb) return fail(HECKA_EINVAL, "head_bwd: a matrix upstream needs Ma == Mb%s");
+  HeadCfg c;
+  if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
+                     scale, A);
+  return check_launch("head_bwd");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {

@@ -9,7 +9,7 @@ import os
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhecka.so')
 _lib = None
 
-_vp, _i, _ll, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t
+_vp, _i, _ll, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t, ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol include/hecka.h declares
 SIGNATURES = {
@@ -19,6 +19,8 @@ SIGNATURES = {
     'hecka_gram_center_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
     'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
+    'hecka_head_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp]),
+    'hecka_head_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp, _vp]),
     'hecka_coef_gamma_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'hecka_combine_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'hecka_rowmix_f32': (_i, [_vp, _vp, _i, _i, _ll, _vp, _vp]),

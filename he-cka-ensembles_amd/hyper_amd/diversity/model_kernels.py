@@ -100,7 +100,37 @@ class FeatureKernel(BaseModelKernel):
 
 
 class _PairwiseHead(BaseModelKernel):
-    """Shared front of the CKA / HE kernels: features -> (cos matrix [M,M], centred Gram)."""
+    """Shared front of the CKA / HE kernels.
+
+    Fast path (`_spec()` is not None: linear kernel, centred, nothing learnable): the whole layer is one
+    `ops.diversity_layer` call.  Otherwise the Gram inner products still come from libhecka and the
+    [M,M] head stays in torch so that learnable eps / arc_eps receive gradients."""
+
+    def _learnable(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def _spec(self):
+        return None
+
+    def _values(self, feats, track, reduce=None):
+        """Fast path only: value matrix [M,M] (reduce=None) or the reduced scalar."""
+        fk = self.feature_kernel
+        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce)
+        track['gram'] = gram
+        return out
+
+    def reduced(self, feats, track, reduce):
+        """mean / sum of this layer's kernel values as a 0-dim tensor (what ModelLayersKernel needs)."""
+        if self._spec() is not None:
+            return self._values(feats, track, reduce)
+        vals = self(None, feats, None, track)
+        return vals.mean() if reduce == 'mean' else vals.sum()
+
+    def _select(self, vals):
+        if self.reduction == 'off_diag':
+            M = vals.shape[0]
+            return vals.reshape(-1).index_select(0, ops.offdiag_index(M, vals.device))
+        return vals
 
     def _cosine(self, feats, eps, track):
         fk = self.feature_kernel
@@ -134,11 +164,16 @@ class CKAModelKernel(_PairwiseHead):
         self.detach_right = detach_right
         self.eps = nn.Parameter(torch.tensor(eps), requires_grad=learnable)
 
+    def _spec(self):
+        if not (self.center and self.feature_kernel.fusable) or self._learnable():
+            return None
+        return ops.HeadSpec(ops.HEAD_CKA, eps=float(self.eps), remove_diag=self.reduction == 'off_diag',
+                            detach_right=self.detach_right)
+
     def forward(self, params, feats, preds, track, layer=None):
-        cos = self._cosine(feats, self.eps, track)
-        if self.reduction == 'off_diag':
-            return cos[~torch.eye(*cos.shape, dtype=torch.bool, device=cos.device)]
-        return cos
+        if self._spec() is not None:
+            return self._select(self._values(feats, track))
+        return self._select(self._cosine(feats, self.eps, track))
 
 
 @register_model_kernel('he')
@@ -168,7 +203,16 @@ class HEModelKernel(_PairwiseHead):
             return arc.item(), eps.item()
         return arc, eps
 
+    def _spec(self):
+        if not (self.center and self.feature_kernel.fusable) or self._learnable():
+            return None
+        return ops.HeadSpec(ops.HEAD_HE, s=self.he_s, eps=float(self.eps), arc_eps=float(self.arc_eps),
+                            use_exp=self.use_exp, abs_vals=self.abs_vals, remove_diag=self.reduction == 'off_diag',
+                            detach_right=self.detach_right)
+
     def forward(self, params, feats, preds, track, layer=None):
+        if self._spec() is not None:
+            return self._select(self._values(feats, track))
         arc, eps = self.get_smoothing()
         cos = self._cosine(feats, eps, track)
         return energy_from_cos(cos, self.he_s, eps, arc, self.reduction == 'off_diag', self.abs_vals, self.use_exp)
@@ -203,8 +247,11 @@ class ModelLayersKernel(BaseModelKernel):
         out = None
         for index, feat in enumerate(feats.values()):
             kern = self.layer_kernel[index] if self.different_kernels else self.layer_kernel
-            term = self.layer_weighting.get_weight(index, total) * self.apply_reduction(
-                kern(params, feat, pred, layer_track[index]))
+            if self.reduction in ('mean', 'sum') and isinstance(kern, _PairwiseHead):
+                value = kern.reduced(feat, layer_track[index], self.reduction)   # reduced inside the head kernel
+            else:
+                value = self.apply_reduction(kern(params, feat, pred, layer_track[index]))
+            term = self.layer_weighting.get_weight(index, total) * value
             out = term if out is None else out + term
         track['layer_track'] = layer_track
         return out

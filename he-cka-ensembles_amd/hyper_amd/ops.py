@@ -204,3 +204,84 @@ class CenterRows(torch.autograd.Function):
 
 def center_rows(G):
     return CenterRows.apply(G)
+
+
+# ------------------------------------------------------------------------- fused layer op
+HEAD_CKA, HEAD_HE = 0, 1
+F_USE_EXP, F_ABS_VALS, F_REMOVE_DIAG, F_DETACH_RIGHT = 1, 2, 4, 8
+
+
+class HeadSpec(object):
+    """Non-learnable head hyper-parameters, passed by value to the head kernels."""
+
+    def __init__(self, kind, s=2.0, eps=1e-6, arc_eps=1e-3, use_exp=False, abs_vals=False, remove_diag=True,
+                 detach_right=False):
+        self.kind, self.s, self.eps, self.arc_eps = int(kind), float(s), abs(float(eps)), abs(float(arc_eps))
+        self.flags = ((F_USE_EXP if use_exp else 0) | (F_ABS_VALS if abs_vals else 0) |
+                      (F_REMOVE_DIAG if remove_diag else 0) | (F_DETACH_RIGHT if detach_right else 0))
+        self.remove_diag = bool(remove_diag)
+
+    def args(self):
+        return (self.kind, self.s, self.eps, self.arc_eps, self.flags)
+
+
+class DiversityLayer(torch.autograd.Function):
+    """One tracked layer of the diversity loss, entirely in libhecka:
+         X [M,B,P] -> centred Gram C -> S = <C_i,C_j> -> cos -> (energy) -> value matrix / reduced scalar.
+
+    reduce=None  : returns (val [M,M], C)   - val_ij for every ordered pair (diagonal included)
+    reduce='mean'|'sum': returns (scalar, C) - over the off-diagonal pairs (remove_diag) or all pairs
+    backward (from dval [M,M] or the scalar's gradient): head_bwd -> combine -> dX = W X."""
+
+    @staticmethod
+    def forward(ctx, X, spec, detach_diag, reduce):
+        _check_features(X)
+        X = X.contiguous()
+        L = _lib.lib()
+        M = X.shape[0]
+        C, cvec = centered_gram(X)
+        S = pairwise_inner(C)
+        nsq = torch.diagonal(S).contiguous()
+        st = _stream()
+        if reduce is None:
+            out = torch.empty((M, M), device=X.device, dtype=torch.float32)
+            _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), _p(out), None, 1.0, st), 'head_fwd')
+            ctx.scale = 1.0
+        else:
+            count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
+            ctx.scale = 1.0 / count
+            out = torch.empty((), device=X.device, dtype=torch.float32)
+            _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), None, _p(out), ctx.scale, st), 'head_fwd')
+        ctx.save_for_backward(X, C, cvec, S, nsq)
+        ctx.spec, ctx.detach_diag, ctx.reduced = spec, bool(detach_diag), reduce is not None
+        ctx.mark_non_differentiable(C)
+        return out, C
+
+    @staticmethod
+    def backward(ctx, dout, _dC):
+        X, C, cvec, S, nsq = ctx.saved_tensors
+        L = _lib.lib()
+        M = X.shape[0]
+        A = torch.empty((M, M), device=X.device, dtype=torch.float32)
+        dout = dout.contiguous().float()
+        up_mat, up_scalar = (None, _p(dout)) if ctx.reduced else (_p(dout), None)
+        _lib.check(L.hecka_head_bwd_f32(_p(S), _p(nsq), M, M, 0, *ctx.spec.args(), up_mat, up_scalar, ctx.scale, _p(A),
+                                        _stream()), 'head_bwd')
+        return gram_backward(A, C, cvec, X, ctx.detach_diag), None, None, None
+
+
+def diversity_layer(X, spec, detach_diag=True, reduce=None):
+    return DiversityLayer.apply(X, spec, detach_diag, reduce)
+
+
+_OFFDIAG_INDEX = {}
+
+
+def offdiag_index(M, device):
+    """Flat indices of the off-diagonal entries of an [M,M] matrix in row-major order (what the
+    reference's boolean mask `m[~eye]` selects), cached so that no nonzero()/host sync happens per step."""
+    key = (M, str(device))
+    if key not in _OFFDIAG_INDEX:
+        idx = torch.arange(M * M, device=device).view(M, M)
+        _OFFDIAG_INDEX[key] = idx[~torch.eye(M, dtype=torch.bool, device=device)].contiguous()
+    return _OFFDIAG_INDEX[key]

@@ -54,6 +54,28 @@ size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K);
 int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K,
                        float* S, void* ws, size_t ws_bytes, void* stream);
 
+/* Pairwise head on the [Ma,Mb] matrix of inner products (rows = this GPU's members starting at global
+ * index row_offset, columns = all members; nsq[Mb] = squared Frobenius norms of all members = diag S):
+ *   cos_ij = S_ij / ((sqrt(nsq_i)+eps)(sqrt(nsq_j)+eps))                       unit_vector_rows, __init__.py:24-30
+ *   kind 0 (cka): value = cos                                                   pairwise_cossim, __init__.py:33-56
+ *   kind 1 (he) : theta = arccos([|cos|]/(1+arc_eps)); value = energy(theta)    hyperspherical_energy, __init__.py:108-144
+ *                 energy: s==0 log(1/(theta+eps)+eps) | s==1 1/(theta+eps) | use_exp exp(-(s theta+eps)) | (1+eps)/(theta^s+eps)
+ * fwd: val[Ma,Mb] (may be NULL) and *sum_out = scale * sum of values (diagonal pair skipped with REMOVE_DIAG;
+ *      sum_out may be NULL) - the reduction of ModelLayersKernel.apply_reduction (model_kernels.py:439-444).
+ * bwd: coefficient matrix A[Ma,Mb] of dC_i = sum_j A_ij C_j for upstream dLoss/dvalue_ij =
+ *      (up_mat ? up_mat[i,j] : 1) * (up_scalar ? *up_scalar : 1) * scale; includes the Jacobian of the
+ *      normalisation and DETACH_RIGHT (gradient through the left factor only).  Replaces autograd through
+ *      __init__.py:24-30,108-144.  eps / arc_eps are passed by absolute value (model_kernels.py:291-300). */
+#define HECKA_HEAD_USE_EXP 1
+#define HECKA_HEAD_ABS_VALS 2
+#define HECKA_HEAD_REMOVE_DIAG 4
+#define HECKA_HEAD_DETACH_RIGHT 8
+int hecka_head_fwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row_offset, int kind, double s,
+                       double eps, double arc_eps, int flags, float* val, float* sum_out, double scale, void* stream);
+int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row_offset, int kind, double s,
+                       double eps, double arc_eps, int flags, const float* up_mat, const float* up_scalar,
+                       double scale, float* A, void* stream);
+
 /* gamma[i,b] = sum_j A[i,j] cvec[j,b]   (A [Ma,Mb], cvec [Mb,B], gamma [Ma,B]). */
 int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int B,
                          float* gamma, void* stream);

@@ -162,3 +162,40 @@ def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
         assert abs(out.item() - ref.item()) <= RTOL * abs(ref.item()), (out.item(), ref.item())
         err = float((x.grad.double() - xo.grad).abs().max() / xo.grad.abs().max())
         assert err <= RTOL, err
+
+
+def test_learnable_head_matches_autograd_oracle():
+    """learnable=True keeps the [M,M] head in torch: loss, dX, d eps and d arc_eps vs the oracle's autograd."""
+    from oracle import hecka_ref as R
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from collections import OrderedDict
+    dev = _dev()
+    torch.manual_seed(11)
+    X = torch.randn(6, 40, 24)
+    cfg = {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031, 'learnable': True,
+           'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}}
+    kern = build_model_kernel(cfg).to(dev)
+    x = X.to(dev).requires_grad_(True)
+    out = kern(None, x, None, OrderedDict()).mean()
+    out.backward()
+    xo = X.double().requires_grad_(True)
+    eps = torch.tensor(R.f32(0.0025), dtype=torch.float64, requires_grad=True)
+    arc = torch.tensor(R.f32(0.031), dtype=torch.float64, requires_grad=True)
+    ref = R.he_layer(xo, eps=eps, arc_eps=arc, detach_diag=True).mean()
+    ref.backward()
+    assert abs(out.item() - ref.item()) <= RTOL * abs(ref.item())
+    assert _relerr(x.grad.cpu().numpy(), xo.grad.numpy()) <= RTOL
+    assert abs(kern.eps.grad.item() - eps.grad.item()) <= 1e-4 * abs(eps.grad.item())
+    assert abs(kern.arc_eps.grad.item() - arc.grad.item()) <= 1e-4 * abs(arc.grad.item())
+
+
+def test_errors_are_loud():
+    """Bad arguments come back as error codes / exceptions, never as silent fallbacks."""
+    from hyper_amd import _lib, ops
+    L = _lib.lib()
+    assert L.hecka_colmean_f32(None, 1, 1, 1, None, None) == -1
+    assert b'null' in L.hecka_last_error()
+    with pytest.raises(RuntimeError):
+        ops.centered_gram_pairwise(torch.randn(2, 4, 3))          # CPU tensor: no CPU path
+    with pytest.raises(RuntimeError):
+        ops.centered_gram_pairwise(torch.randn(2, 4, 3, device=_dev()).double())
