@@ -95,6 +95,7 @@ class CenteredGramPairwise(torch.autograd.Function):
         ctx.save_for_backward(X, C, cvec)
         ctx.detach_diag, ctx.left_only = bool(detach_diag), bool(left_only)
         ctx.mark_non_differentiable(C)
+        ctx.set_materialize_grads(False)
         return S, nsq, C
 
     @staticmethod
@@ -255,11 +256,14 @@ class DiversityLayer(torch.autograd.Function):
         ctx.save_for_backward(X, C, cvec, S, nsq)
         ctx.spec, ctx.detach_diag, ctx.reduced = spec, bool(detach_diag), reduce is not None
         ctx.mark_non_differentiable(C)
+        ctx.set_materialize_grads(False)   # no zeros_like(C) for the non-differentiable by-product
         return out, C
 
     @staticmethod
     def backward(ctx, dout, _dC):
         X, C, cvec, S, nsq = ctx.saved_tensors
+        if dout is None:
+            return torch.zeros_like(X), None, None, None
         L = _lib.lib()
         M = X.shape[0]
         A = torch.empty((M, M), device=X.device, dtype=torch.float32)
