@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/hecka.h"
 #include "gemm_mfma.hpp"
@@ -96,11 +97,11 @@ struct CenterPro {
   }
 };
 
-template <int T, bool VEC>
+template <int T, bool VEC, bool FULL>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_kernel(GemmOperands g, const float* __restrict__ sbar,
                                                                   float* __restrict__ C, float* __restrict__ cvec,
                                                                   int ntile) {
-  using Tile = GemmTile<T, T, false, VEC, CenterPro<T, VEC>>;
+  using Tile = GemmTile<T, T, false, VEC, CenterPro<T, VEC>, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[T], cB[T];
 
@@ -157,9 +158,9 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_kernel(GemmOperands g
 // ------------------------------------------------------------------------------------------
 // (3) pairwise S = Ca Cb^T, split-K partials + fixed-order reduction.  HBM-bound: reads C once.
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool FULL>
 __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, float* __restrict__ part, int tilesN) {
-  using Tile = GemmTile<64, 64, false, VEC, NoPrologue>;
+  using Tile = GemmTile<64, 64, false, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
   const int z = blockIdx.z;
@@ -215,10 +216,10 @@ __global__ void coef_gamma_kernel(const float* __restrict__ A, const float* __re
 // ------------------------------------------------------------------------------------------
 // MODE 0: plain row mix  out = A V   (backward of the generic pairwise inner product)
 // MODE 1: symmetrised Gram gradient W (above)
-template <bool VEC, int MODE>
+template <bool VEC, int MODE, bool FULL>
 __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, const float* __restrict__ gamma, int B,
                                                               int detach_diag, float* __restrict__ W, int tilesN) {
-  using Tile = GemmTile<64, 128, true, VEC, NoPrologue>;
+  using Tile = GemmTile<64, 128, true, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
   NoPrologue pro;
@@ -242,9 +243,9 @@ __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, co
 // ------------------------------------------------------------------------------------------
 // (6) dX_m = W_m X_m.  MFMA-bound: 2*B*B*P flop per member.
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool FULL>
 __global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, float* __restrict__ dX, int tilesN) {
-  using Tile = GemmTile<128, 128, true, VEC, NoPrologue>;
+  using Tile = GemmTile<128, 128, true, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
   const int m = blockIdx.y;
@@ -472,13 +473,16 @@ int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P
   g.K = P; g.kchunk = P;
   const bool vec = (P % 4 == 0) && aligned16(X) && aligned16(sbar);
   hipStream_t st = (hipStream_t)stream;
-  const int T = 128;
+  constexpr int T = 128;
   const int ntile = (B + T - 1) / T;
   dim3 grid(ntile * (ntile + 1) / 2, M);
-  if (vec)
-    hipLaunchKernelGGL((gram_center_kernel<128, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
+  const bool full = vec && (B % T == 0) && (P % kBK == 0);
+  if (full)
+    hipLaunchKernelGGL((gram_center_kernel<128, true, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
+  else if (vec)
+    hipLaunchKernelGGL((gram_center_kernel<128, true, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
   else
-    hipLaunchKernelGGL((gram_center_kernel<128, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
+    hipLaunchKernelGGL((gram_center_kernel<128, false, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
   return check_launch("gram_center");
 }
 
@@ -509,10 +513,13 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   dim3 grid(tilesM * tilesN, 1, nsplit);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
-  if (vec)
-    hipLaunchKernelGGL(pairwise_kernel<true>, grid, dim3(kThreads), 0, st, g, part, tilesN);
+  const bool full = vec && (Ma % 64 == 0) && (Mb % 64 == 0) && (K % kBK == 0);
+  if (full)
+    hipLaunchKernelGGL((pairwise_kernel<true, true>), grid, dim3(kThreads), 0, st, g, part, tilesN);
+  else if (vec)
+    hipLaunchKernelGGL((pairwise_kernel<true, false>), grid, dim3(kThreads), 0, st, g, part, tilesN);
   else
-    hipLaunchKernelGGL(pairwise_kernel<false>, grid, dim3(kThreads), 0, st, g, part, tilesN);
+    hipLaunchKernelGGL((pairwise_kernel<false, false>), grid, dim3(kThreads), 0, st, g, part, tilesN);
   int rc = check_launch("pairwise");
   if (rc) return rc;
   const int n = Ma * Mb;
@@ -545,17 +552,19 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   const int tilesM = (Ma + 63) / 64, tilesN = (int)((N + 127) / 128);
   dim3 grid(tilesM * tilesN);
   hipStream_t st = (hipStream_t)stream;
+  const bool full = vec && (Ma % 64 == 0) && (N % 128 == 0) && (Mb % kBK == 0);
+#define HECKA_COMBINE(V, MD, F) \
+  hipLaunchKernelGGL((combine_kernel<V, MD, F>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN)
   if (mode == 1) {
-    if (vec)
-      hipLaunchKernelGGL((combine_kernel<true, 1>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
-    else
-      hipLaunchKernelGGL((combine_kernel<false, 1>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+    if (full) HECKA_COMBINE(true, 1, true);
+    else if (vec) HECKA_COMBINE(true, 1, false);
+    else HECKA_COMBINE(false, 1, false);
   } else {
-    if (vec)
-      hipLaunchKernelGGL((combine_kernel<true, 0>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
-    else
-      hipLaunchKernelGGL((combine_kernel<false, 0>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN);
+    if (full) HECKA_COMBINE(true, 0, true);
+    else if (vec) HECKA_COMBINE(true, 0, false);
+    else HECKA_COMBINE(false, 0, false);
   }
+#undef HECKA_COMBINE
   return check_launch("combine");
 }
 
@@ -639,10 +648,13 @@ int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, floa
   const int tilesM = (B + 127) / 128, tilesN = (P + 127) / 128;
   dim3 grid(tilesM * tilesN, M);
   hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL(gram_bwd_kernel<true>, grid, dim3(kThreads), 0, st, g, dX, tilesN);
+  const bool full = vec && (B % 128 == 0) && (P % 128 == 0);
+  if (full)
+    hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
+  else if (vec)
+    hipLaunchKernelGGL((gram_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   else
-    hipLaunchKernelGGL(gram_bwd_kernel<false>, grid, dim3(kThreads), 0, st, g, dX, tilesN);
+    hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   return check_launch("gram_bwd");
 }
 
