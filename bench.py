@@ -73,18 +73,24 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get('HECKA_FORCE_SHARDED') == '1'   # rehearse the RCCL path with world_size 1
+    if world > 1 or force_sharded:
         import torch.distributed as dist
+        if force_sharded and 'RANK' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
 
     from hyper_amd import ops
     from hyper_amd.diversity.model_kernels import build_model_kernel
 
-    if world > 1:
-        raise NotImplementedError('member-sharded multi-GPU path lands in hyper_amd.parallel (next step)')
-    members = slice(0, M)
+    if M % world:
+        raise SystemExit('M=%d members do not shard over %d GPUs' % (M, world))
+    members = slice(rank * (M // world), (rank + 1) * (M // world))   # this rank's ensemble members
     feats = make_feats(dev, members)
     kern = build_model_kernel(CFG).to(dev)
+    if world > 1 or force_sharded:
+        from hyper_amd.parallel import ShardedModelLayersKernel
+        kern = ShardedModelLayersKernel(kern)        # all_gather of centred Grams over RCCL, one scalar all_reduce
     xs = [f.requires_grad_(True) for f in feats]
     fdict = OrderedDict((str(i), x) for i, x in enumerate(xs))
 
@@ -119,14 +125,15 @@ def main():
         ms = 1e3 * dt / args.steps
         # dominant kernel: dX = W X (gram_bwd_kernel), 2*M*B*B*P flop per launch (SURVEY.md 8d per-unit figure)
         kms = sum(a.elapsed_time(b) for a, b, _ in prof['gram_bwd'])
-        kfl = sum(fl for _, _, fl in prof['gram_bwd'])
+        kfl = sum(fl for _, _, fl in prof['gram_bwd'])      # rank 0's launches (M/world members each)
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         flops_eval = sum(4.0 * M * B * B * p + 4.0 * M * M * B * B for p in DIMS)
         out = {
             'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
+            'config': {'parallelism': 'members sharded %d-way, all_gather of centred Grams' % world if world > 1 else 'single GPU',
+                       'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
                                    'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
                        'loss': float(loss.item()), 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},
             'roofline': {'bound': 'mfma', 'kernel': 'gram_bwd_kernel (dX = W X, fp32 MFMA)', 'achieved': ach,

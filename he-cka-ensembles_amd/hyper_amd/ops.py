@@ -289,3 +289,25 @@ def offdiag_index(M, device):
         idx = torch.arange(M * M, device=device).view(M, M)
         _OFFDIAG_INDEX[key] = idx[~torch.eye(M, dtype=torch.bool, device=device)].contiguous()
     return _OFFDIAG_INDEX[key]
+
+
+# ------------------------------------------------------------------------- head kernels, raw
+def head_forward(S, nsq, row_offset, spec, scale, want_values=False):
+    """S [Ma,Mb], nsq [Mb] -> (values [Ma,Mb] or None, scale * sum of selected values as a 0-dim tensor)."""
+    Ma, Mb = S.shape
+    val = torch.empty((Ma, Mb), device=S.device, dtype=torch.float32) if want_values else None
+    tot = torch.empty((), device=S.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_head_fwd_f32(_p(S), _p(nsq), Ma, Mb, int(row_offset), *spec.args(),
+                                            _p(val) if want_values else None, _p(tot), float(scale), _stream()), 'head_fwd')
+    return val, tot
+
+
+def head_backward(S, nsq, row_offset, spec, up_scalar, scale, up_mat=None):
+    """Coefficient matrix A [Ma,Mb] of dC_i = sum_j A_ij C_j."""
+    Ma, Mb = S.shape
+    A = torch.empty((Ma, Mb), device=S.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_head_bwd_f32(_p(S), _p(nsq), Ma, Mb, int(row_offset), *spec.args(),
+                                            _p(up_mat) if up_mat is not None else None,
+                                            _p(up_scalar) if up_scalar is not None else None, float(scale), _p(A),
+                                            _stream()), 'head_bwd')
+    return A

@@ -1,0 +1,69 @@
+"""CPU stand-in for hyper_amd.ops used ONLY by the gloo tests of the sharding logic: the five device
+stages restated with the oracle's closed-form numpy code (oracle/closed_form.py)."""
+import numpy as np
+import torch
+
+from oracle import closed_form as CF
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def centered_gram(X):
+    C, c, _ = CF.forward_stats(X.double().numpy())
+    return _t(C), _t(c)
+
+
+def pairwise_inner(Ca, Cb=None):
+    Cb = Ca if Cb is None else Cb
+    return Ca.reshape(Ca.shape[0], -1) @ Cb.reshape(Cb.shape[0], -1).t()
+
+
+def _head(S, nsq, r0, spec, up):
+    """Embed the local rows in a full [M,M] problem (other rows zero upstream) and reuse CF.head."""
+    Ma, Mb = S.shape
+    F_USE_EXP, F_ABS, F_RM, F_DR = 1, 2, 4, 8
+    n = np.sqrt(nsq.numpy())
+    d = n + spec.eps
+    cos = S.numpy() / np.outer(d[r0:r0 + Ma], d)
+    if spec.kind == 0:
+        val, slope = cos, np.ones_like(cos)
+    else:
+        a = np.abs(cos) if spec.flags & F_ABS else cos
+        z = a / (1.0 + spec.arc_eps)
+        val, de = CF.energy_and_slope(np.arccos(z), spec.s, spec.eps, bool(spec.flags & F_USE_EXP))
+        slope = de * (-1.0 / np.sqrt(1.0 - z * z)) / (1.0 + spec.arc_eps)
+        if spec.flags & F_ABS:
+            slope = slope * np.sign(cos)
+    mask = np.ones_like(cos)
+    if spec.flags & F_RM:
+        mask[np.arange(Ma), r0 + np.arange(Ma)] = 0.0
+    return val, slope, mask, n, d
+
+
+def head_forward(S, nsq, r0, spec, scale, want_values=False):
+    val, _, mask, _, _ = _head(S, nsq, r0, spec, None)
+    return (_t(val) if want_values else None), torch.tensor(float((val * mask).sum() * scale), dtype=torch.float64)
+
+
+def head_backward(S, nsq, r0, spec, up_scalar, scale, up_mat=None):
+    val, slope, mask, n, d = _head(S, nsq, r0, spec, None)
+    Ma, Mb = S.shape
+    G = slope * mask * float(up_scalar) * scale
+    Gs = G if spec.flags & 8 else 2.0 * G          # uniform upstream: G_ji == G_ij
+    A = Gs / np.outer(d[r0:r0 + Ma], d)
+    vg = (Gs * S.numpy() / d[None, :]).sum(axis=1)
+    A[np.arange(Ma), r0 + np.arange(Ma)] += -vg / (n[r0:r0 + Ma] * d[r0:r0 + Ma] ** 2)
+    return _t(A)
+
+
+def gram_backward(A, C_all, cv_all, X, detach_diag):
+    A, C, c, Xn = A.numpy(), C_all.numpy(), cv_all.numpy(), X.double().numpy()
+    B = Xn.shape[1]
+    dC = np.einsum('mj,jab->mab', A, C)
+    gam = A @ c
+    W = 2.0 * dC + gam[:, :, None] - gam[:, None, :]
+    if detach_diag:
+        W = W * (1.0 - np.eye(B))[None]
+    return _t(np.einsum('mab,mbp->map', W, Xn)).to(X.dtype)

@@ -199,3 +199,35 @@ def test_errors_are_loud():
         ops.centered_gram_pairwise(torch.randn(2, 4, 3))          # CPU tensor: no CPU path
     with pytest.raises(RuntimeError):
         ops.centered_gram_pairwise(torch.randn(2, 4, 3, device=_dev()).double())
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_sharded_stages_on_gpu(world):
+    """The member-sharded stages (hyper_amd.parallel) with the HIP kernels, emulated in one process:
+    every 'rank' computes its row block from the full Gram set; the pieces must equal the unsharded result."""
+    from hyper_amd import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    M, B, P = 8, 64, 48
+    X = torch.randn(M, B, P, device=dev)
+    spec = ops.HeadSpec(ops.HEAD_HE, s=2.0, eps=0.0025, arc_eps=0.031)
+    C, cvec = ops.centered_gram(X)
+    S = ops.pairwise_inner(C)
+    nsq = torch.diagonal(S).contiguous()
+    scale = 1.0 / (M * (M - 1))
+    _, full = ops.head_forward(S, nsq, 0, spec, scale)
+    one = torch.ones((), device=dev)
+    A = ops.head_backward(S, nsq, 0, spec, one, scale)
+    dX = ops.gram_backward(A, C, cvec, X, True)
+    Ml, tot = M // world, 0.0
+    for r in range(world):
+        rows = slice(r * Ml, (r + 1) * Ml)
+        Sl = ops.pairwise_inner(C[rows].contiguous(), C)
+        assert _relerr(Sl.cpu().numpy(), S[rows].cpu().double().numpy()) <= 1e-6
+        _, part = ops.head_forward(Sl, nsq, r * Ml, spec, scale)
+        tot += part.item()
+        Al = ops.head_backward(Sl, nsq, r * Ml, spec, one, scale)
+        assert _relerr(Al.cpu().numpy(), A[rows].cpu().double().numpy()) <= 1e-5
+        dXl = ops.gram_backward(Al, C, cvec, X[rows].contiguous(), True)
+        assert _relerr(dXl.cpu().numpy(), dX[rows].cpu().double().numpy()) <= 1e-5
+    assert abs(tot - full.item()) <= 1e-6 * abs(full.item())

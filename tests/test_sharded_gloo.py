@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the member-sharded loss (hyper_amd.parallel) on the CPU: the sharding /
+collective logic with an oracle-backed compute backend must reproduce the single-process oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, cfgname, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import cpu_backend
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from hyper_amd.parallel import ShardedModelLayersKernel
+    from collections import OrderedDict
+    cfg, feats = _case(cfgname)
+    M = feats[0].shape[0]
+    Ml = M // world
+    xs = [f[rank * Ml:(rank + 1) * Ml].clone().requires_grad_(True) for f in feats]
+    kern = ShardedModelLayersKernel(build_model_kernel(cfg), backend=cpu_backend)
+    loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+    loss.backward()
+    torch.save({'loss': loss.detach(), 'grads': [x.grad for x in xs]}, '%s.%d' % (out, rank))
+    dist.destroy_process_group()
+
+
+def _case(name):
+    torch.manual_seed(21)
+    feats = [torch.randn(6, 12, p, dtype=torch.float64) for p in (9, 20)]
+    lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031),
+          'he_exp_dr': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True, detach_right=True),
+          'cka': dict(name='cka', eps=1e-6)}[name]
+    lk['feature_kernel'] = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
+    cfg = {'name': 'model_layers', 'layer_kernel': lk, 'reduction': 'mean',
+           'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2]}}
+    return cfg, feats
+
+
+@pytest.mark.parametrize('name', ['he', 'he_exp_dr', 'cka'])
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_matches_single_process_oracle(name, world, tmp_path):
+    from oracle import hecka_ref as R
+    out = str(tmp_path / 'res')
+    port = 29600 + (os.getpid() + world * 7 + len(name)) % 300
+    mp.start_processes(_worker, args=(world, port, name, out), nprocs=world, join=True, start_method='spawn')
+    cfg, feats = _case(name)
+    xo = [f.clone().requires_grad_(True) for f in feats]
+    ref = R.run_config(cfg, xo)
+    ref.backward()
+    Ml = feats[0].shape[0] // world
+    for r in range(world):
+        res = torch.load('%s.%d' % (out, r), weights_only=True)
+        assert abs(res['loss'].item() - ref.item()) <= 1e-10 * abs(ref.item())
+        for g, x in zip(res['grads'], xo):
+            exp = x.grad[r * Ml:(r + 1) * Ml]
+            assert np.abs(g.numpy() - exp.numpy()).max() <= 1e-9 * np.abs(exp.numpy()).max()
