@@ -425,6 +425,133 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// (9) non-linear Gram kernels (cossim, rbf) on top of the raw Gram G = X X^T.  Row-wise HBM passes.
+//     kind 1 cossim: K'_ab = G_ab / sqrt(G_aa G_bb)                      (kernels.py:145-169)
+//     kind 2 rbf   : d_ab = -2 G_ab + G_aa + G_bb, K'_ab = exp(-d_ab / (2 h_m))   (kernels.py:198-286)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// One workgroup per (row a, member m): C[a,:] = K'[a,:] - mean (center) or K'[a,:]; rmean, gdiag side outputs.
+__global__ __launch_bounds__(256) void gram_transform_kernel(const float* __restrict__ G, int B, int kind,
+                                                             const float* __restrict__ hband, int center,
+                                                             float* __restrict__ C, float* __restrict__ rmean,
+                                                             float* __restrict__ gdiag) {
+  __shared__ float red[4];
+  const int a = blockIdx.x, m = blockIdx.y;
+  const float* g = G + (size_t)m * B * B;
+  const float gaa = g[(size_t)a * B + a];
+  const float inv2h = kind == 2 ? 1.0f / (2.0f * hband[m]) : 0.f;
+  float* out = C + ((size_t)m * B + a) * B;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float gab = g[(size_t)a * B + b], gbb = g[(size_t)b * B + b];
+    float k;
+    if (kind == 1) {
+      k = gab / sqrtf(gaa * gbb);
+    } else {
+      float d = -2.0f * gab + gaa;
+      d += gbb;
+      k = expf(-d * inv2h);
+    }
+    out[b] = k;
+    s += k;
+  }
+  const float mean = center ? block_sum_f(s, red) / (float)B : 0.f;
+  if (center)
+    for (int b = threadIdx.x; b < B; b += 256) out[b] -= mean;   // each thread revisits its own elements
+  if (threadIdx.x == 0) {
+    rmean[(size_t)m * B + a] = mean;
+    gdiag[(size_t)m * B + a] = gaa;
+  }
+}
+
+// Exact lower median (torch.median: sorted[(n-1)/2]) of the B*B squared distances of one member, by 4-pass
+// 8-bit radix select on order-preserving keys; h_m = param * median / (2 log(B+1)) in fp32 like the reference.
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void rbf_bandwidth_kernel(const float* __restrict__ G, int B, float param,
+                                                            float* __restrict__ hband) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_prefix, sel_k;
+  const int m = blockIdx.x;
+  const float* g = G + (size_t)m * B * B;
+  const long long n = (long long)B * B;
+  if (threadIdx.x == 0) {
+    sel_prefix = 0u;
+    sel_k = (unsigned)((n - 1) / 2);
+  }
+  unsigned mask = 0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned prefix = sel_prefix;
+    for (long long e = threadIdx.x; e < n; e += 1024) {
+      const int a = (int)(e / B), b = (int)(e - (long long)a * B);
+      float d = -2.0f * g[e] + g[(size_t)a * B + a];
+      d += g[(size_t)b * B + b];
+      const unsigned key = f2key(d);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned k = sel_k, bin = 0;
+      for (; bin < 256; ++bin) {
+        if (k < hist[bin]) break;
+        k -= hist[bin];
+      }
+      sel_k = k;
+      sel_prefix = prefix | (bin << shift);
+    }
+    mask |= 0xFFu << shift;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const unsigned key = sel_prefix;
+    const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+    const float med = __uint_as_float(u);
+    const float w = (float)(2.0 * log((double)B + 1.0));
+    hband[m] = (param * med) / w;
+  }
+}
+
+// Backward of the transform, in place on Dsym = dK' + dK'^T (diagonal already zero): W = dG + dG^T.
+//   cossim: W_ab = Dsym_ab / sqrt(G_aa G_bb),  W_aa = -(1/G_aa) sum_{b!=a} Dsym_ab K'_ab
+//   rbf   : W_ab = Dsym_ab K'_ab / h,          W_aa = -(1/h)    sum_{b!=a} Dsym_ab K'_ab
+// K'_ab = Cown_ab + rmean_a (rmean == NULL: Cown already holds K').
+__global__ __launch_bounds__(256) void gram_transform_bwd_kernel(float* __restrict__ D, const float* __restrict__ Cown,
+                                                                 const float* __restrict__ rmean,
+                                                                 const float* __restrict__ gdiag,
+                                                                 const float* __restrict__ hband, int B, int kind) {
+  __shared__ float red[4];
+  const int a = blockIdx.x, m = blockIdx.y;
+  float* d = D + ((size_t)m * B + a) * B;
+  const float* c = Cown + ((size_t)m * B + a) * B;
+  const float ra = rmean ? rmean[(size_t)m * B + a] : 0.f;
+  const float gaa = gdiag[(size_t)m * B + a];
+  const float invh = kind == 2 ? 1.0f / hband[m] : 0.f;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (b == a) continue;
+    const float ds = d[b], kp = c[b] + ra;
+    s += ds * kp;
+    d[b] = kind == 1 ? ds / sqrtf(gaa * gdiag[(size_t)m * B + b]) : ds * kp * invh;
+  }
+  const float tot = block_sum_f(s, red);
+  if (threadIdx.x == 0) d[a] = kind == 1 ? -tot / gaa : -tot * invh;
+}
+
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -631,6 +758,35 @@ int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
                      scale, A);
   return check_launch("head_bwd");
+}
+
+int hecka_rbf_bandwidth_f32(const float* G, int M, int B, float param, float* hband, void* stream) {
+  clear_error();
+  if (!G || !hband) return fail(HECKA_EINVAL, "rbf_bandwidth: null pointer%s");
+  if (M <= 0 || B <= 0) return fail(HECKA_EINVAL, "rbf_bandwidth: bad size%s");
+  hipLaunchKernelGGL(rbf_bandwidth_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, G, B, param, hband);
+  return check_launch("rbf_bandwidth");
+}
+
+int hecka_gram_transform_f32(const float* G, int M, int B, int kind, const float* hband, int center, float* C,
+                             float* rmean, float* gdiag, void* stream) {
+  clear_error();
+  if (!G || !C || !rmean || !gdiag || (kind == 2 && !hband)) return fail(HECKA_EINVAL, "gram_transform: null pointer%s");
+  if (G == C) return fail(HECKA_EINVAL, "gram_transform: in-place not supported%s");
+  if (M <= 0 || B <= 0 || M > 65535 || (kind != 1 && kind != 2)) return fail(HECKA_EINVAL, "gram_transform: bad argument%s");
+  hipLaunchKernelGGL(gram_transform_kernel, dim3(B, M), dim3(256), 0, (hipStream_t)stream, G, B, kind, hband, center, C,
+                     rmean, gdiag);
+  return check_launch("gram_transform");
+}
+
+int hecka_gram_transform_bwd_f32(float* D, const float* Cown, const float* rmean, const float* gdiag, const float* hband,
+                                 int M, int B, int kind, void* stream) {
+  clear_error();
+  if (!D || !Cown || !gdiag || (kind == 2 && !hband)) return fail(HECKA_EINVAL, "gram_transform_bwd: null pointer%s");
+  if (M <= 0 || B <= 0 || M > 65535 || (kind != 1 && kind != 2)) return fail(HECKA_EINVAL, "gram_transform_bwd: bad argument%s");
+  hipLaunchKernelGGL(gram_transform_bwd_kernel, dim3(B, M), dim3(256), 0, (hipStream_t)stream, D, Cown, rmean, gdiag,
+                     hband, B, kind);
+  return check_launch("gram_transform_bwd");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {

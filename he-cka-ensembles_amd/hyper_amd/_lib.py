@@ -26,6 +26,9 @@ SIGNATURES = {
     'hecka_rowmix_f32': (_i, [_vp, _vp, _i, _i, _ll, _vp, _vp]),
     'hecka_center_rows_f32': (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     'hecka_symmetrize_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'hecka_rbf_bandwidth_f32': (_i, [_vp, _i, _i, ctypes.c_float, _vp, _vp]),
+    'hecka_gram_transform_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    'hecka_gram_transform_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'hecka_gram_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 

@@ -6,8 +6,8 @@ This is the UN-FUSED entry: each function is its own differentiable op, so Gram,
 pairwise head each make a pass over [M,B,B].  The model kernels (model_kernels.py) use the fused
 path (ops.centered_gram_pairwise) instead whenever the configuration allows it.
 
-Built so far: `linear`.  `cossim` and `rbf` (the other two kernels the shipped YAMLs use) are the
-next widening step; `log`, `hyperenergy`, `laplacian` and `learned` are not used by any config."""
+Built: `linear`, `cossim`, `rbf` (every kernel the shipped YAMLs use); `log`, `hyperenergy`, `laplacian`
+and `learned` are used by no config and raise NotImplementedError."""
 import torch
 
 from .. import ops
@@ -35,6 +35,33 @@ def linear_gram(X, Y=None, detach_diag=True, readd=True, *args, **kwargs):
     return ops.linear_gram(X, detach_diag)
 
 
+def _scalar(v):
+    return float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+
+
+def cossim_gram(X, Y=None, detach_diag=True, readd=True, *args, **kwargs):
+    """K_ab = x_a.x_b / sqrt(|x_a|^2 |x_b|^2); the diagonal is identically 1 and carries no gradient, so
+    detach_diag does not change the result.  (`eps` is accepted and ignored, as in the reference.)"""
+    _only_self(Y, X)
+    if detach_diag and not readd:
+        raise NotImplementedError('readd_diag=False (zeroed Gram diagonal) is not built; no shipped config uses it')
+    return ops.transformed_gram_ad(X, ops.GramSpec(ops.GRAM_COSSIM))
+
+
+def rbf_gram(X, Y=None, param=1.0, median=True, detach_diag=True, readd=True, grad_var=None, median_ma=None,
+             median_update=True, detach_right=False, *args, **kwargs):
+    """K = exp(-d / (2 h_m)), d = squared distances, h_m = param * median(d_m) / (2 log(B+1)) (no gradient
+    through the bandwidth) or param^2 with median=False."""
+    _only_self(Y, X)
+    if median_ma is not None or grad_var is not None or detach_right:
+        raise NotImplementedError('EMA bandwidth / grad_var / detach_right rbf variants (SVGD kernels) are not built')
+    if detach_diag and not readd:
+        raise NotImplementedError('readd_diag=False (zeroed Gram diagonal) is not built; no shipped config uses it')
+    if isinstance(param, torch.Tensor) and param.requires_grad:
+        raise NotImplementedError('a learnable rbf `param` is not built')
+    return ops.transformed_gram_ad(X, ops.GramSpec(ops.GRAM_RBF, _scalar(param), median))
+
+
 def _not_built(name):
     def fn(*args, **kwargs):
         raise NotImplementedError('Gram kernel `%s` is not built in hyper_amd yet' % name)
@@ -44,9 +71,9 @@ def _not_built(name):
 MAPS = {
     'linear': linear_gram,
     'log': _not_built('log'),
-    'cossim': _not_built('cossim'),
+    'cossim': cossim_gram,
     'hyperenergy': _not_built('hyperenergy'),
-    'rbf': _not_built('rbf'),
+    'rbf': rbf_gram,
     'laplacian': _not_built('laplacian'),
 }
 

@@ -74,7 +74,19 @@ class FeatureKernel(BaseModelKernel):
     @property
     def fusable(self):
         """True when the Gram -> centre -> pairwise chain can run as the single fused op."""
-        return self.kernel == 'linear' and (self.readd or not self.detach_diag) and not self.args and not self.kwargs
+        return self.gram_spec() is not None
+
+    def gram_spec(self):
+        """ops.GramSpec for the fused layer op, or None when this configuration needs the un-fused path."""
+        if (self.detach_diag and not self.readd) or self.args or any(p.requires_grad for p in self.params.values()):
+            return None
+        if self.kernel == 'linear' and not self.kwargs:
+            return ops.GramSpec(ops.GRAM_LINEAR)
+        if self.kernel == 'cossim' and not self.kwargs:
+            return ops.GramSpec(ops.GRAM_COSSIM)
+        if self.kernel == 'rbf' and set(self.kwargs) <= {'median'}:
+            return ops.GramSpec(ops.GRAM_RBF, float(self.params['param']), self.kwargs.get('median', True))
+        return None
 
     @staticmethod
     def flatten(feats, flat_second=True):
@@ -115,7 +127,7 @@ class _PairwiseHead(BaseModelKernel):
     def _values(self, feats, track, reduce=None):
         """Fast path only: value matrix [M,M] (reduce=None) or the reduced scalar."""
         fk = self.feature_kernel
-        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce)
+        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce, fk.gram_spec())
         track['gram'] = gram
         return out
 
@@ -134,7 +146,7 @@ class _PairwiseHead(BaseModelKernel):
 
     def _cosine(self, feats, eps, track):
         fk = self.feature_kernel
-        if self.center and fk.fusable:
+        if self.center and fk.fusable and fk.kernel == 'linear':
             X = fk.flatten(feats)
             S, nsq, gram = ops.centered_gram_pairwise(X, fk.detach_diag, self.detach_right)
         else:
@@ -237,6 +249,25 @@ class ModelLayersKernel(BaseModelKernel):
             return model_grams.sum()
         return model_grams
 
+    # Layers are independent until the final weighted sum, so on the GPU each layer's kernel chain is
+    # enqueued on its own HIP stream (round-robin over `num_streams`): the tail of one layer's Gram launch
+    # and its small [M,M] kernels overlap with another layer's MFMA work.  Autograd replays every node on
+    # the stream it ran on in forward, so the backward overlaps the same way.  0/1 = everything in order on
+    # the current stream.
+    num_streams = 4
+    _streams = {}
+
+    def _side_streams(self, device, n):
+        key = (device.index, n)
+        if key not in ModelLayersKernel._streams:
+            ModelLayersKernel._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return ModelLayersKernel._streams[key]
+
+    def _layer_value(self, kern, params, feat, pred, ltrack):
+        if self.reduction in ('mean', 'sum') and isinstance(kern, _PairwiseHead):
+            return kern.reduced(feat, ltrack, self.reduction)   # reduced inside the head kernel
+        return self.apply_reduction(kern(params, feat, pred, ltrack))
+
     def forward(self, params, feats, pred, track):
         total = len(feats)
         if total == 0:
@@ -244,13 +275,31 @@ class ModelLayersKernel(BaseModelKernel):
         self.layer_weighting.reset_total()
         self.layer_weighting.save_total(total)
         layer_track = [OrderedDict() for _ in range(total)]
+        flist = list(feats.values())
+        kerns = [self.layer_kernel[i] if self.different_kernels else self.layer_kernel for i in range(total)]
+        nstream = min(self.num_streams, total) if flist[0].is_cuda else 0
+        values = []
+        if nstream > 1:
+            main = torch.cuda.current_stream(flist[0].device)
+            streams = self._side_streams(flist[0].device, nstream)
+            for st in streams:
+                st.wait_stream(main)
+            for index, feat in enumerate(flist):
+                st = streams[index % nstream]
+                with torch.cuda.stream(st):
+                    v = self._layer_value(kerns[index], params, feat, pred, layer_track[index])
+                    v.record_stream(main)
+                    g = layer_track[index].get('gram')
+                    if g is not None:
+                        g.record_stream(main)
+                values.append(v)
+            for st in streams:
+                main.wait_stream(st)
+        else:
+            for index, feat in enumerate(flist):
+                values.append(self._layer_value(kerns[index], params, feat, pred, layer_track[index]))
         out = None
-        for index, feat in enumerate(feats.values()):
-            kern = self.layer_kernel[index] if self.different_kernels else self.layer_kernel
-            if self.reduction in ('mean', 'sum') and isinstance(kern, _PairwiseHead):
-                value = kern.reduced(feat, layer_track[index], self.reduction)   # reduced inside the head kernel
-            else:
-                value = self.apply_reduction(kern(params, feat, pred, layer_track[index]))
+        for index, value in enumerate(values):
             term = self.layer_weighting.get_weight(index, total) * value
             out = term if out is None else out + term
         track['layer_track'] = layer_track

@@ -226,6 +226,64 @@ class HeadSpec(object):
         return (self.kind, self.s, self.eps, self.arc_eps, self.flags)
 
 
+GRAM_LINEAR, GRAM_COSSIM, GRAM_RBF = 0, 1, 2
+
+
+class GramSpec(object):
+    """Which feature Gram a layer uses: linear (fused centred MFMA kernel) or a row-wise transform of the raw
+    Gram (cossim, rbf with the median-heuristic bandwidth `param * median / (2 log(B+1))` or `param^2`)."""
+
+    def __init__(self, kind=GRAM_LINEAR, param=1.0, median=True):
+        self.kind, self.param, self.median = int(kind), float(param), bool(median)
+
+
+def raw_gram(X):
+    """G = X X^T [M,B,B] (the centred-Gram kernel with zero column means)."""
+    L = _lib.lib()
+    M, B, P = X.shape
+    zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
+    G = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+    scratch = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), M, B, P, _p(G), _p(scratch), _stream()), 'gram')
+    return G
+
+
+def transformed_gram(X, gspec, center):
+    """cossim / rbf Gram (row-centred when `center`): returns (C, rmean, gdiag, hband)."""
+    L = _lib.lib()
+    M, B, _ = X.shape
+    G = raw_gram(X)
+    st = _stream()
+    hband = torch.empty((M,), device=X.device, dtype=torch.float32)
+    if gspec.kind == GRAM_RBF:
+        if gspec.median:
+            _lib.check(L.hecka_rbf_bandwidth_f32(_p(G), M, B, gspec.param, _p(hband), st), 'rbf_bandwidth')
+        else:
+            hband.fill_(gspec.param ** 2)
+    C = torch.empty_like(G)
+    rmean = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    gdiag = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    _lib.check(L.hecka_gram_transform_f32(_p(G), M, B, gspec.kind, _p(hband), int(bool(center)), _p(C), _p(rmean),
+                                          _p(gdiag), st), 'gram_transform')
+    return C, rmean, gdiag, hband
+
+
+def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec):
+    """dX for a cossim / rbf layer from the coefficient matrix A (dC_i = sum_j A_ij C_j)."""
+    L = _lib.lib()
+    M, B, P = X.shape
+    st = _stream()
+    rho = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    W = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+    dX = torch.empty_like(X)
+    _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(rmean), M, M, B, _p(rho), st), 'coef_gamma')
+    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), st), 'combine')
+    _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(C), _p(rmean), _p(gdiag), _p(hband), M, B, gspec.kind, st),
+               'gram_transform_bwd')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+    return dX
+
+
 class DiversityLayer(torch.autograd.Function):
     """One tracked layer of the diversity loss, entirely in libhecka:
          X [M,B,P] -> centred Gram C -> S = <C_i,C_j> -> cos -> (energy) -> value matrix / reduced scalar.
@@ -235,12 +293,17 @@ class DiversityLayer(torch.autograd.Function):
     backward (from dval [M,M] or the scalar's gradient): head_bwd -> combine -> dX = W X."""
 
     @staticmethod
-    def forward(ctx, X, spec, detach_diag, reduce):
+    def forward(ctx, X, spec, detach_diag, reduce, gspec):
         _check_features(X)
         X = X.contiguous()
         L = _lib.lib()
         M = X.shape[0]
-        C, cvec = centered_gram(X)
+        if gspec is None or gspec.kind == GRAM_LINEAR:
+            C, cvec = centered_gram(X)
+            aux = (cvec,)
+        else:
+            C, rmean, gdiag, hband = transformed_gram(X, gspec, True)
+            aux = (rmean, gdiag, hband)
         S = pairwise_inner(C)
         nsq = torch.diagonal(S).contiguous()
         st = _stream()
@@ -253,17 +316,18 @@ class DiversityLayer(torch.autograd.Function):
             ctx.scale = 1.0 / count
             out = torch.empty((), device=X.device, dtype=torch.float32)
             _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), None, _p(out), ctx.scale, st), 'head_fwd')
-        ctx.save_for_backward(X, C, cvec, S, nsq)
-        ctx.spec, ctx.detach_diag, ctx.reduced = spec, bool(detach_diag), reduce is not None
+        ctx.save_for_backward(X, C, S, nsq, *aux)
+        ctx.spec, ctx.detach_diag, ctx.reduced, ctx.gspec = spec, bool(detach_diag), reduce is not None, gspec
         ctx.mark_non_differentiable(C)
         ctx.set_materialize_grads(False)   # no zeros_like(C) for the non-differentiable by-product
         return out, C
 
     @staticmethod
     def backward(ctx, dout, _dC):
-        X, C, cvec, S, nsq = ctx.saved_tensors
+        X, C, S, nsq = ctx.saved_tensors[:4]
+        aux = ctx.saved_tensors[4:]
         if dout is None:
-            return torch.zeros_like(X), None, None, None
+            return torch.zeros_like(X), None, None, None, None
         L = _lib.lib()
         M = X.shape[0]
         A = torch.empty((M, M), device=X.device, dtype=torch.float32)
@@ -271,11 +335,15 @@ class DiversityLayer(torch.autograd.Function):
         up_mat, up_scalar = (None, _p(dout)) if ctx.reduced else (_p(dout), None)
         _lib.check(L.hecka_head_bwd_f32(_p(S), _p(nsq), M, M, 0, *ctx.spec.args(), up_mat, up_scalar, ctx.scale, _p(A),
                                         _stream()), 'head_bwd')
-        return gram_backward(A, C, cvec, X, ctx.detach_diag), None, None, None
+        if len(aux) == 1:
+            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag)
+        else:
+            dX = transformed_gram_backward(A, C, aux[0], aux[1], aux[2], X, ctx.gspec)
+        return dX, None, None, None, None
 
 
-def diversity_layer(X, spec, detach_diag=True, reduce=None):
-    return DiversityLayer.apply(X, spec, detach_diag, reduce)
+def diversity_layer(X, spec, detach_diag=True, reduce=None, gspec=None):
+    return DiversityLayer.apply(X, spec, detach_diag, reduce, gspec)
 
 
 _OFFDIAG_INDEX = {}
@@ -311,3 +379,34 @@ def head_backward(S, nsq, row_offset, spec, up_scalar, scale, up_mat=None):
                                             _p(up_scalar) if up_scalar is not None else None, float(scale), _p(A),
                                             _stream()), 'head_bwd')
     return A
+
+
+class TransformedGram(torch.autograd.Function):
+    """Un-fused functional API: X -> K' (cossim / rbf Gram, not centred); backward dK' -> dX."""
+
+    @staticmethod
+    def forward(ctx, X, gspec):
+        _check_features(X)
+        X = X.contiguous()
+        K, rmean, gdiag, hband = transformed_gram(X, gspec, False)
+        ctx.save_for_backward(X, K, gdiag, hband)
+        ctx.gspec = gspec
+        return K
+
+    @staticmethod
+    def backward(ctx, dK):
+        X, K, gdiag, hband = ctx.saved_tensors
+        L = _lib.lib()
+        M, B, P = X.shape
+        st = _stream()
+        W = torch.empty_like(K)
+        dX = torch.empty_like(X)
+        _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
+        _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(K), None, _p(gdiag), _p(hband), M, B, ctx.gspec.kind, st),
+                   'gram_transform_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+        return dX, None
+
+
+def transformed_gram_ad(X, gspec):
+    return TransformedGram.apply(X, gspec)

@@ -103,6 +103,22 @@ int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, 
  * of dX = W X; backward of torch.bmm(X, X^T) + detach_diagonal (hyper/diversity/kernels.py:122-125, 76-104). */
 int hecka_symmetrize_f32(const float* G, int M, int B, int detach_diag, float* W, void* stream);
 
+/* Non-linear Gram kernels on top of the raw Gram G = X X^T (hecka_gram_center_f32 with sbar = 0):
+ *   kind 1 cossim: K'_ab = G_ab / sqrt(G_aa G_bb)                     cossim_gram, hyper/diversity/kernels.py:145-169
+ *   kind 2 rbf   : d_ab = -2 G_ab + G_aa + G_bb, K' = exp(-d/(2 h_m))   rbf_gram, kernels.py:198-286 (Y=None, no EMA)
+ * hecka_rbf_bandwidth_f32: h_m = param * median(d_m) / (2 log(B+1)), median = exact LOWER median of the B*B
+ *   distances (torch.median), kernels.py:250-269; radix select, no gradient (as in the reference).
+ * hecka_gram_transform_f32: C = K' - rowmean(K') when `center` (center_gram, kernels.py:335-345) else K';
+ *   side outputs rmean[M,B] (row means, 0 if !center) and gdiag[M,B] (G_aa).  Out of place (C != G).
+ * hecka_gram_transform_bwd_f32: in place on D = dK' + dK'^T with zero diagonal (hecka_combine_f32 with
+ *   gamma = A rmean, or hecka_symmetrize_f32): D <- dG + dG^T, ready for hecka_gram_bwd_f32.  The diagonal of
+ *   K' carries no gradient for either kernel (cossim: K'_aa = 1, rbf: d_aa = 0), detach_diag or not. */
+int hecka_rbf_bandwidth_f32(const float* G, int M, int B, float param, float* hband, void* stream);
+int hecka_gram_transform_f32(const float* G, int M, int B, int kind, const float* hband, int center, float* C,
+                             float* rmean, float* gdiag, void* stream);
+int hecka_gram_transform_bwd_f32(float* D, const float* Cown, const float* rmean, const float* gdiag,
+                                 const float* hband, int M, int B, int kind, void* stream);
+
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122) on fp32 MFMA. */
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream);
