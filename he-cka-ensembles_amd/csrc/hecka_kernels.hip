@@ -207,6 +207,7 @@ __global__ void coef_gamma_kernel(const float* __restrict__ A, const float* __re
   const int i = blockIdx.y;
   if (b >= B) return;
   float s = 0.f;
+#pragma unroll 8
   for (int j = 0; j < Mb; ++j) s += A[(size_t)i * Mb + j] * cvec[(size_t)j * B + b];
   gamma[(size_t)i * B + b] = s;
 }
@@ -348,22 +349,25 @@ __device__ __forceinline__ void head_value(const HeadCfg& c, double cosv, double
   dval_dcos = d;
 }
 
-__device__ __forceinline__ double block_sum_256(double v, double* red) {
+constexpr int kHeadThreads = 1024;  // one workgroup, 16 waves: the head is latency-bound fp64 transcendental work
+__device__ __forceinline__ double block_sum_head(double v, double* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  const double t = red[0] + red[1] + red[2] + red[3];
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kHeadThreads / 64; ++w) t += red[w];
   __syncthreads();
   return t;
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+__global__ __launch_bounds__(kHeadThreads) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
                                                        int Ma, int Mb, HeadCfg c, float* __restrict__ val,
                                                        float* __restrict__ sum_out, double scale) {
-  __shared__ double red[4];
+  __shared__ double red[kHeadThreads / 64];
   double acc = 0.0;
-  for (int e = threadIdx.x; e < Ma * Mb; e += 256) {
+  for (int e = threadIdx.x; e < Ma * Mb; e += kHeadThreads) {
     const int i = e / Mb, j = e - i * Mb;
     const double di = sqrt((double)nsq[c.row_offset + i]) + c.eps, dj = sqrt((double)nsq[j]) + c.eps;
     double v, dv;
@@ -371,19 +375,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     if (val) val[e] = (float)v;
     if (!(c.remove_diag && j == c.row_offset + i)) acc += v;
   }
-  const double tot = block_sum_256(acc, red);
+  const double tot = block_sum_head(acc, red);
   if (sum_out && threadIdx.x == 0) *sum_out = (float)(tot * scale);
 }
 
 // upstream dLoss/dvalue_ij = (up_mat ? up_mat[i,j] : 1) * (up_scalar ? *up_scalar : 1) * scale.
 // A matrix upstream needs the transposed entry too, so it requires Ma == Mb (single GPU).
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
                                                        int Ma, int Mb, HeadCfg c, const float* __restrict__ up_mat,
                                                        const float* __restrict__ up_scalar, double scale,
                                                        float* __restrict__ A) {
   const double us = (up_scalar ? (double)*up_scalar : 1.0) * scale;
   // phase 1: Gs_ij = G_ij (+ G_ji)   (cos is symmetric, so G_ji differs from G_ij only through up_mat)
-  for (int e = threadIdx.x; e < Ma * Mb; e += 256) {
+  for (int e = threadIdx.x; e < Ma * Mb; e += kHeadThreads) {
     const int i = e / Mb, j = e - i * Mb;
     const int gi = c.row_offset + i;
     double g = 0.0;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __syncthreads();
   // phase 2: one wave per row: A_ij = Gs_ij/(d_i d_j);  A_ii = Gs_ii eps/d_i^3 - (sum_{j!=i} Gs_ij S_ij/d_j)/(n_i d_i^2)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < Ma; i += 4) {
+  for (int i = wave; i < Ma; i += kHeadThreads / 64) {
     const int gi = c.row_offset + i;
     const double ni = sqrt((double)nsq[gi]), di = ni + c.eps;
     double vg = 0.0;
@@ -550,6 +554,30 @@ __global__ __launch_bounds__(256) void gram_transform_bwd_kernel(float* __restri
   }
   const float tot = block_sum_f(s, red);
   if (threadIdx.x == 0) d[a] = kind == 1 ? -tot / gaa : -tot * invh;
+}
+
+// ------------------------------------------------------------------------------------------
+// (10) batched-weight Linear: C[b] = alpha * A[b] op(B[b]) + beta * bias[b][col]   (grouped GEMM on fp32 MFMA)
+//      fwd  : y = x W^T       (NT)   A = x [N,I],  B = W [O,I]         hyper/layers/linear.py:144-155 (baddbmm)
+//      dgrad: dx = dy W       (NN)   A = dy [N,O], B = W [O,I]
+//      wgrad: dW = dy^T x     (NT on host-transposed operands)
+//      batch stride 0 shares an operand across members (2-D input expanded over the ensemble).
+// ------------------------------------------------------------------------------------------
+template <int T, bool NN, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void bgemm_kernel(GemmOperands g, float* __restrict__ C, int tilesN, float alpha,
+                                                            const float* __restrict__ bias, float beta) {
+  using Tile = GemmTile<T, T, NN, VEC, NoPrologue>;
+  __shared__ typename Tile::Smem sm;
+  const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN, b = blockIdx.y;
+  NoPrologue pro;
+  Tile tile;
+  tile.run(sm, g, g.A + (size_t)b * g.strideA, g.B + (size_t)b * g.strideB, ti * T, tj * T, 0, g.K, pro);
+  float* out = C + (size_t)b * g.rowsA * g.colsB;
+  const float* bb = bias ? bias + (size_t)b * g.colsB : nullptr;
+  tile.for_each([&](int lr, int lc, float v) {
+    const int row = ti * T + lr, col = tj * T + lc;
+    if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = alpha * v + (bb ? beta * bb[col] : 0.f);
+  });
 }
 
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
@@ -743,7 +771,7 @@ int hecka_head_fwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   if (!S || !nsq || (!val && !sum_out)) return fail(HECKA_EINVAL, "head_fwd: null pointer%s");
   HeadCfg c;
   if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(1), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
   return check_launch("head_fwd");
 }
 
@@ -755,7 +783,7 @@ int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   if (up_mat && Ma != Mb) return fail(HECKA_EINVAL, "head_bwd: a matrix upstream needs Ma == Mb%s");
   HeadCfg c;
   if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
                      scale, A);
   return check_launch("head_bwd");
 }
@@ -787,6 +815,37 @@ int hecka_gram_transform_bwd_f32(float* D, const float* Cown, const float* rmean
   hipLaunchKernelGGL(gram_transform_bwd_kernel, dim3(B, M), dim3(256), 0, (hipStream_t)stream, D, Cown, rmean, gdiag,
                      hband, B, kind);
   return check_launch("gram_transform_bwd");
+}
+
+int hecka_bgemm_f32(const float* A, const float* Bm, float* C, int batch, int rows, int cols, int K, long long strideA,
+                    long long strideB, int nn, float alpha, const float* bias, float beta, void* stream) {
+  clear_error();
+  if (!A || !Bm || !C) return fail(HECKA_EINVAL, "bgemm: null pointer%s");
+  if (batch <= 0 || rows <= 0 || cols <= 0 || K <= 0 || batch > 65535) return fail(HECKA_EINVAL, "bgemm: bad size%s");
+  GemmOperands g;
+  g.A = A; g.B = Bm;
+  g.strideA = strideA; g.strideB = strideB;
+  g.lda = K; g.ldb = nn ? cols : K;
+  g.rowsA = rows; g.colsB = cols;
+  g.K = K; g.kchunk = K;
+  const bool vec = (K % 4 == 0) && (!nn || cols % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) && aligned16(A) &&
+                   aligned16(Bm);
+  const bool big = rows >= 256 && cols >= 256;
+  const int T = big ? 128 : 64;
+  const int tilesM = (rows + T - 1) / T, tilesN = (cols + T - 1) / T;
+  dim3 grid(tilesM * tilesN, batch);
+  hipStream_t st = (hipStream_t)stream;
+#define HECKA_BGEMM(TT, NNF, V) \
+  hipLaunchKernelGGL((bgemm_kernel<TT, NNF, V>), grid, dim3(kThreads), 0, st, g, C, tilesN, alpha, bias, beta)
+  if (big) {
+    if (nn) { if (vec) HECKA_BGEMM(128, true, true); else HECKA_BGEMM(128, true, false); }
+    else    { if (vec) HECKA_BGEMM(128, false, true); else HECKA_BGEMM(128, false, false); }
+  } else {
+    if (nn) { if (vec) HECKA_BGEMM(64, true, true); else HECKA_BGEMM(64, true, false); }
+    else    { if (vec) HECKA_BGEMM(64, false, true); else HECKA_BGEMM(64, false, false); }
+  }
+#undef HECKA_BGEMM
+  return check_launch("bgemm");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {

@@ -1,0 +1,135 @@
+"""Training "methods" on the hot path (hyper/diversity/methods.py: registry :18-39, ParticleMethods `mle`
+:42-164, RepulsiveKernel `repulsive_kernel` :309-360).  `svgd` / `function_svgd` are out of scope
+(SURVEY.md 8f #2)."""
+import copy
+import traceback
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ..util.collections import flatten_keys
+from .losses import build_loss
+from .model_kernels import WeightKernelUnsupported, build_model_kernel
+
+AVAILABLE_METHODS = {}
+
+
+def register_method(name):
+    def deco(cls):
+        AVAILABLE_METHODS[name] = cls
+        return cls
+    return deco
+
+
+def build_method(config):
+    config = copy.deepcopy(config)
+    if 'name' not in config:
+        raise RuntimeError('method config needs a `name` key')
+    cls = AVAILABLE_METHODS[config.pop('name')]
+    return cls(**cls.from_config(config))
+
+
+@register_method('mle')
+class ParticleMethods(nn.Module):
+    def __init__(self, num, model_kernel=None, ind_loss=None, ood_loss=None, beta_ind=1.0, beta_ood=1.0, l2_reg=None,
+                 learnable_beta=False):
+        super().__init__()
+        self.num, self.ind_loss, self.ood_loss, self.model_kernel = num, ind_loss, ood_loss, model_kernel
+        self.l2_reg = (l2_reg / 2.0) if l2_reg is not None else None
+        self.beta_ind = nn.Parameter(torch.tensor(beta_ind, dtype=torch.float32), requires_grad=learnable_beta)
+        self.beta_ood = nn.Parameter(torch.tensor(beta_ood, dtype=torch.float32), requires_grad=learnable_beta)
+
+    def batch_start(self, trainer, X, Y):
+        trainer.optim_hyper.zero_grad()
+        trainer.optim_method.zero_grad()
+
+    def batch_end(self, trainer, X, Y):
+        try:   # non-finite gradients skip the step instead of poisoning the weights
+            if trainer.clip is not None:
+                torch.nn.utils.clip_grad_norm_(trainer.hyper.parameters(), trainer.clip, norm_type=2, error_if_nonfinite=True)
+            trainer.optim_hyper.step()
+            trainer.optim_method.step()
+        except RuntimeError as err:
+            traceback.print_exc()
+            print('Clip error! %s' % err)
+
+    def forward(self, trainer, params, shared_params, track, x, gt, ignore_ood_loss=False, step=0):
+        track['ind_loss'] = self.ind_loss(self.num, x, track['pred_ind'], gt) if self.ind_loss is not None else None
+        track['loss'] = torch.abs(self.beta_ind) * track['ind_loss']
+        if not ignore_ood_loss and self.ood_loss is not None:
+            if track['pred_ood'] is None:
+                raise RuntimeError('OOD loss was defined but no OOD predictions were passed')
+            track = self.forward_ood(trainer, params, shared_params, track, x, gt)
+        if self.l2_reg is not None:
+            l2 = 0.0
+            for name, value in flatten_keys(params).items():
+                if 'affine' in name or 'bias' in name or 'skip' in name:
+                    continue
+                l2 = l2 + torch.square(value).view(value.shape[0], -1).mean(dim=1).mean()
+            track['loss'] = track['loss'] + self.l2_reg * l2
+        return track
+
+    def forward_ood(self, trainer, params, shared_params, track, x, gt):
+        track['ood_loss'] = self.ood_loss(self.num, x, track['pred_ood'], gt)
+        ood = torch.abs(self.beta_ood) * track['ood_loss']
+        track['loss'] = track['loss'] + ood if 'loss' in track else ood
+        return track
+
+    @torch.no_grad()
+    def test(self, trainer, params, shared_params, track, x, gt):
+        return track['loss'], {}
+
+    def backward(self, trainer, params, shared_params, track, x, gt, retain_graph=False, create_graph=False, inputs=None):
+        track['loss'].backward(retain_graph=retain_graph, create_graph=create_graph, inputs=inputs)
+        return track['loss'], {}
+
+    @staticmethod
+    def from_config(config):
+        config['model_kernel'] = build_model_kernel(config['model_kernel']) if 'model_kernel' in config else None
+        for key in ('ind_loss', 'ood_loss'):
+            if key in config:
+                config[key] = build_loss(config[key])
+        return config
+
+
+@register_method('repulsive_kernel')
+class RepulsiveKernel(ParticleMethods):
+    """loss = |beta_ind| CE + c_warm |gamma| rep (+ c_warm |gamma_ood| rep_ood); a NaN repulsive term counts as 0."""
+
+    def __init__(self, num, model_kernel, ind_loss, ood_loss=None, gamma=1.0, model_kernel_ood=None, beta_ind=1.0,
+                 beta_ood=1.0, gamma_ood=1.0, warmup=0, l2_reg=None, learnable_beta=False, learnable=False):
+        super().__init__(num, model_kernel, ind_loss, ood_loss, beta_ind=beta_ind, l2_reg=l2_reg, beta_ood=beta_ood,
+                         learnable_beta=learnable_beta)
+        self.gamma = nn.Parameter(torch.tensor(gamma, dtype=torch.float32), requires_grad=learnable)
+        self.use_ood = ood_loss is not None or model_kernel_ood is not None
+        if self.use_ood:
+            self.gamma_ood = nn.Parameter(torch.tensor(gamma_ood, dtype=torch.float32), requires_grad=learnable)
+        self.model_kernel_ood = model_kernel_ood
+        self.warmup = warmup
+        if isinstance(model_kernel, WeightKernelUnsupported):
+            raise ValueError('Weight kernels are not supported for feature repulsion')
+
+    def forward(self, trainer, params, shared_params, track, x, gt, ignore_ood_loss=False, step=0):
+        track = super().forward(trainer, params, shared_params, track, x, gt, ignore_ood_loss=ignore_ood_loss, step=step)
+        flat_params = flatten_keys(params)
+        warm = 1.0
+        if trainer.training and self.warmup is not None and step is not None and step < self.warmup:
+            warm = (1e-8 + step) / self.warmup
+        track['ind_kernel'] = OrderedDict()
+        rep = self.model_kernel(flat_params, track['feats_ind'], track['pred_ind'], track['ind_kernel'])
+        track['ind_rep_loss'] = rep
+        track['loss'] = track['loss'] + warm * torch.abs(self.gamma) * torch.nan_to_num(rep, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+        if self.use_ood and self.model_kernel_ood is not None:
+            track['ood_kernel'] = OrderedDict()
+            rep_ood = self.model_kernel_ood(flat_params, track['feats_ood'], track['pred_ood'], track['ood_kernel'])
+            track['ood_rep_loss'] = rep_ood
+            track['loss'] = track['loss'] + warm * torch.abs(self.gamma_ood) * torch.nan_to_num(rep_ood, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+        return track
+
+    @staticmethod
+    def from_config(config):
+        config = ParticleMethods.from_config(config)
+        if 'model_kernel_ood' in config:
+            config['model_kernel_ood'] = build_model_kernel(config['model_kernel_ood'])
+        return config

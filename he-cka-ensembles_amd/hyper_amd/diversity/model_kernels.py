@@ -312,3 +312,18 @@ class ModelLayersKernel(BaseModelKernel):
         config['layer_kernel'] = [build_model_kernel(k) for k in lk] if isinstance(lk, list) else build_model_kernel(lk)
         config['layer_weighting'] = build_weighting(config['layer_weighting'])
         return config
+
+
+class WeightKernelUnsupported(BaseModelKernel):
+    """Placeholder type for the reference's `weight` / `function` kernels (SVGD methods, out of scope)."""
+
+
+def _not_built_kernel(name):
+    class _K(WeightKernelUnsupported):
+        def __init__(self, *a, **k):
+            raise NotImplementedError('model kernel `%s` belongs to the SVGD methods and is not built in hyper_amd' % name)
+    return _K
+
+
+AVAILABLE_KERNELS['weight'] = _not_built_kernel('weight')
+AVAILABLE_KERNELS['function'] = _not_built_kernel('function')

@@ -1,0 +1,157 @@
+"""Fixed ensemble "generator" (hyper/generators/ensemble.py:13-107, hyper/layers/generators/fixed.py:12-75,
+forward / feature_split protocol of hyper/generators/base.py:357-491): holds nn.Parameter[size, *shape] per
+generated layer, selects members by index and hands every layer ONE flat row per member."""
+import copy
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ..layers.module import GenModule, ParametersGroup, build_gen_module
+from ..util.collections import DefaultOrderedDict, flatten_keys
+
+AVAILABLE_GENERATORS = {}
+
+
+def register_generator(name):
+    def deco(cls):
+        AVAILABLE_GENERATORS[name] = cls
+        return cls
+    return deco
+
+
+def build_generator(config):
+    config = copy.deepcopy(config)
+    if 'name' not in config:
+        raise RuntimeError('generator config needs a `name` key')
+    cls = AVAILABLE_GENERATORS[config.pop('name')]
+    return cls(**cls.from_config(config))
+
+
+class EnsembleParametersGroupGenerator(nn.Module):
+    def __init__(self, definition, fixed_size):
+        super().__init__()
+        if not isinstance(definition, ParametersGroup):
+            raise ValueError('an ensemble generator needs a ParametersGroup (known parameter shapes)')
+        if isinstance(fixed_size, float) or fixed_size <= 0:
+            raise ValueError('Fixed size must be a non-negative integer')
+        self.definition, self.fixed_size = [definition], fixed_size   # list: not a registered sub-module
+        members = [definition.gen_initialized_params() for _ in range(fixed_size)]
+        self.fixed_parameters = nn.ParameterDict()   # filled one by one: declaration order (weight, bias) matters
+        for name in members[0]:
+            self.fixed_parameters[name] = nn.Parameter(torch.stack([m[name] for m in members]))
+        self.flat_size = sum(int(v[0].numel()) for v in self.fixed_parameters.values())
+
+    def get_expected_input_size(self):
+        return self.fixed_size
+
+    def random(self, num, std=1.0, device=None):
+        return torch.empty(num, self.flat_size, device=device).normal_(0.0, std)
+
+    def forward(self, codes):
+        idx = codes.long().ravel()
+        return torch.cat([v.index_select(0, idx).view(len(idx), -1) for v in self.fixed_parameters.values()], dim=1)
+
+
+@register_generator('ensemble')
+class FixedEnsembleModel(nn.Module):
+    def __init__(self, target, ensemble_size):
+        super().__init__()
+        self.target, self.size = target, ensemble_size
+        self.gen_defined = target.define_generated_modules()
+        self.layer_generators = nn.ModuleDict()
+        self._assign(self.gen_defined, self.layer_generators)
+
+    def _assign(self, definitions, generators):
+        for name, mod_def in definitions.items():
+            if isinstance(mod_def, dict):
+                generators[name] = nn.ModuleDict()
+                self._assign(mod_def, generators[name])
+            else:
+                generators[name] = EnsembleParametersGroupGenerator(mod_def, self.size)
+
+    def _iter(self, names, generators):
+        for name, gen in generators.items():
+            if isinstance(gen, nn.ModuleDict):
+                yield from self._iter(names + [name], gen)
+            else:
+                yield names + [name], gen
+
+    def get_target(self):
+        return self.target
+
+    def target_parameters(self):
+        return list(self.target.parameters())
+
+    def sample_params(self, size, device=None):
+        if size is None:
+            return torch.arange(0, self.size, device=device, dtype=torch.long)
+        if isinstance(size, (list, set)):
+            return torch.tensor(list(size), device=device, dtype=torch.long)
+        return torch.randperm(self.size, device=device, dtype=torch.long)[:size]
+
+    def forward_params(self, codes, device=None):
+        if isinstance(codes, str):                      # "random members": N(0,1) flat rows
+            params = DefaultOrderedDict()
+            for names, gen in self._iter([], self.layer_generators):
+                params.set_subitems(names, gen.random(int(codes), device=device))
+            return params
+        if isinstance(codes, int):
+            codes = torch.arange(0, codes, device=device, dtype=torch.long)
+        elif codes is None:
+            codes = torch.arange(0, self.size, device=device, dtype=torch.long)
+        assert codes.ndim <= 1, 'Invalid number of code dims. Expecting 1'
+        if torch.any(codes < 0) or torch.any(codes >= self.size):
+            raise ValueError('Invalid model index in codes. Please only select members from indices 0 to %d' % self.size)
+        idx = codes.reshape(-1).long()
+        params = DefaultOrderedDict()
+        for names, gen in self._iter([], self.layer_generators):
+            params.set_subitems(names, gen(idx))
+        return params
+
+    @staticmethod
+    def feature_split(feats, pred=None, ood_N=None, skip_empty=True, detach_feats=None, split_pred_only=False,
+                      already_flat=False):
+        flat = feats if already_flat else flatten_keys(feats)
+        has_ood = ood_N is not None and ood_N > 0
+        f_in, f_ood = OrderedDict(), (OrderedDict() if has_ood else None)
+        for i, (key, feat) in enumerate(flat.items()):
+            if feat is None and skip_empty:
+                continue
+            if detach_feats is not None and i in detach_feats:
+                feat = feat.detach()
+            if has_ood and not split_pred_only:
+                f_ood[key] = feat[:, -ood_N:]
+                feat = feat[:, :-ood_N]
+            f_in[key] = feat
+        p_in, p_ood = pred, None
+        if pred is not None and has_ood:
+            p_in, p_ood = pred[:, :-ood_N], pred[:, -ood_N:]
+        return f_in, p_in, f_ood, p_ood
+
+    def forward_split(self, params, x, ood_N=0, skip_empty=True, detach_feats=None, split_pred_only=False):
+        all_feats, all_pred = self.target(params, x)
+        all_feats = flatten_keys(all_feats)
+        feats, pred, ood_feats, ood_pred = self.feature_split(all_feats, all_pred, ood_N, skip_empty, detach_feats,
+                                                              split_pred_only, already_flat=True)
+        return {'feats': all_feats, 'pred': all_pred, 'feats_ind': feats, 'pred_ind': pred,
+                'feats_ood': ood_feats, 'pred_ood': ood_pred}
+
+    def forward(self, params, x, sample_params=False, ret_params=False, feature_split=False, **split_args):
+        if sample_params:
+            params = self.forward_params(self.sample_params(params, device=x.device))
+        elif not isinstance(params, OrderedDict):
+            params = self.forward_params(params)
+        if feature_split:
+            res = self.forward_split(params, x, **split_args)
+            if ret_params:
+                res['params'] = params
+            return res
+        outs = self.target(params, x)
+        return (params, outs) if ret_params else outs
+
+    @staticmethod
+    def from_config(config):
+        if isinstance(config['target'], dict):
+            config['target'] = build_gen_module(config['target'])
+        return config

@@ -119,6 +119,16 @@ int hecka_gram_transform_f32(const float* G, int M, int B, int kind, const float
 int hecka_gram_transform_bwd_f32(float* D, const float* Cown, const float* rmean, const float* gdiag,
                                  const float* hband, int M, int B, int kind, void* stream);
 
+/* Batched-weight Linear as a grouped GEMM on fp32 MFMA:
+ *   C[b] = alpha * A[b] op(B[b]) + beta * bias[b][col],  C [batch, rows, cols] contiguous
+ *   A[b] = A + b*strideA : [rows, K];  B[b] = B + b*strideB : nn ? [K, cols] : [cols, K];  bias [batch, cols] or NULL.
+ *   strideA / strideB = 0 share that operand across the batch (a 2-D input expanded over the ensemble).
+ * forward  y = baddbmm(b', x, W'^T)   hyper/layers/linear.py:144-155: nn=0, A=x, B=W, alpha=scale, beta=bias_scale
+ * dgrad    dx = dy W'                 nn=1, A=dy, B=W;   wgrad  dW = dy^T x: nn=0 on transposed operands. */
+int hecka_bgemm_f32(const float* A, const float* B, float* C, int batch, int rows, int cols, int K,
+                    long long strideA, long long strideB, int nn, float alpha, const float* bias, float beta,
+                    void* stream);
+
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122) on fp32 MFMA. */
 int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream);

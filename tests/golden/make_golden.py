@@ -131,8 +131,52 @@ def run_case(mk, name, cfg, M, B, shapes, style, dtype):
     return rec
 
 
+TOY = {
+    'hyper': {'name': 'ensemble', 'ensemble_size': 6,
+              'target': {'name': 'mlp', 'activation': 'crater',
+                         'layers': [{'in': 2, 'out': 8}, {'in': 8, 'out': 10}, {'in': 10, 'out': 6}, {'in': 6, 'out': 4}]}},
+    'method': {'name': 'repulsive_kernel', 'num': 6, 'gamma': 7.5, 'warmup': 10, 'beta_ind': 2.25,
+               'model_kernel': layers(he('rbf', he_s=5.0, eps=0.000005, arc_eps=0.00305, params={'param': 5.025}),
+                                      {'name': 'list', 'weights': [0.05, 0.35, 1.0, 0.85]}),
+               'ind_loss': {'name': 'cross_entropy'}},
+}
+
+
+def run_train_step(dtype, tag):
+    """One training step of the toy four-class configuration (configs/toy/fourclass/ens/he-rbf.yml shape, smaller
+    sizes) with the REAL reference: FixedEnsembleModel(MLP) forward, RepulsiveKernel.forward, backward."""
+    import hyper.target.mlp  # noqa: F401  (registers `mlp`)
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    torch.manual_seed(77)
+    hyper = build_generator(TOY['hyper']).to(dtype)
+    method = build_method(TOY['method']).to(dtype)
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(12, 2, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 4, (12,), generator=gen)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=3)
+    track['loss'].backward()
+    rec = {'config': json.dumps(TOY), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 3,
+           'loss': track['loss'].detach().numpy(), 'ind_loss': track['ind_loss'].detach().numpy(),
+           'ind_rep_loss': track['ind_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy(),
+           'feat_keys': json.dumps(list(track['feats_ind'].keys()))}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'toy_train_step_%s.npz' % tag), **rec)
+    print('toy_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']))
+
+
 def main():
     mk = _import_reference()
+    for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        run_train_step(dtype, tag)
     for name, (cfg, M, B, shapes, style) in CASES.items():
         for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
             rec = run_case(mk, name, cfg, M, B, shapes, style, dtype)

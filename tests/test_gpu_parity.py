@@ -225,3 +225,35 @@ def test_sharded_stages_on_gpu(world):
         dXl = ops.gram_backward(Al, C, cvec, X[rows].contiguous(), True)
         assert _relerr(dXl.cpu().numpy(), dX[rows].cpu().double().numpy()) <= 1e-5
     assert abs(tot - full.item()) <= 1e-6 * abs(full.item())
+
+
+def test_toy_train_step_matches_reference_golden():
+    """BASELINE configs[1] shape (toy four-class MLP ensemble, rbf HE repulsion): one training step through
+    hyper_amd's FixedEnsembleModel -> batched Linear (MFMA) -> RepulsiveKernel -> backward, against the step
+    the REAL reference produced (tests/golden/toy_train_step_f64.npz, same weights and batch)."""
+    import json
+    import types
+    import numpy as np
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    import os
+    z = np.load(os.path.join(GOLDEN, 'toy_train_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    assert list(track['feats_ind'].keys()) == json.loads(str(z['feat_keys']))
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
+    track['loss'].backward()
+    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 1e-5
+    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
+    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 5e-5, k
