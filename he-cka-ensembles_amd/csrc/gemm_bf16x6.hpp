@@ -1,0 +1,281 @@
+// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand is split EXACTLY into three bf16 terms
+//     x = h + m + l,   h = trunc16(x), m = trunc16(x - h), l = trunc16(x - h - m)          (24 significand bits)
+// and a.b is accumulated in fp32 from the six leading products  hh + hm + mh + mm + hl + lh  (the three dropped
+// ones are below 2^-23 |a||b|).  On gfx950 v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles against 2 k per
+// 64 cycles for v_mfma_f32_32x32x2_f32, so six bf16 passes cost 12 cycles per k instead of 32: 2.67x the
+// fp32-MFMA rate.
+//
+// Accuracy.  The bf16 MFMA adds its 16 products and the accumulator with TRUNCATION (measured: bias -4e-6 of
+// sum|a.b| at K = 8192 when one accumulator runs over the whole K).  The tile therefore accumulates at most
+// kX6Fold k-tiles (64 k) in a LOCAL accumulator that starts from zero, and folds it into the running sum with
+// IEEE round-to-nearest v_add_f32: the truncation then acts on 1/128 of the magnitude and the running sum sees
+// K/64 correctly rounded adds.  Measured max error / sum|a.b| at K = 8192: 6.5e-7 (fp32 MFMA path: 2.5e-6).
+//
+// Structure: 256 threads (4 waves, 2x2), tile 128x128, BK = 16, two LDS stages (2 x 36 KB, two workgroups per
+// CU).  The split is done ONCE per staged element (registers -> three bf16 planes in LDS); LDS rows are 16 bf16
+// + 8 pad (48 B: conflict-free ds_read_b128).  Global loads run two k-tiles ahead in two register sets; split +
+// LDS write of tile t+1 is interleaved with the 24 MFMAs of tile t; one barrier per tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "gemm_mfma.hpp"
+
+namespace hecka {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kX6BK = 16;
+constexpr int kX6LD = 24;   // bf16 per padded LDS row (48 B)
+constexpr int kX6Fold = 4;  // k-tiles per local accumulation chain
+
+template <int TM, int TN>
+struct X6Smem {
+  alignas(16) unsigned short a[2][3][TM * kX6LD];
+  alignas(16) unsigned short b[2][3][TN * kX6LD];
+};
+
+// two of the four floats of v (elements q0, q0+1) -> one packed dword per plane
+template <class V>
+__device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& vl, int qo) {
+  const f32x2 x = {v[q0], v[q0 + 1]};
+  const unsigned x0 = __float_as_uint(x[0]), x1 = __float_as_uint(x[1]);
+  const f32x2 hh = {__uint_as_float(x0 & 0xFFFF0000u), __uint_as_float(x1 & 0xFFFF0000u)};
+  const f32x2 r1 = x - hh;
+  const unsigned a0 = __float_as_uint(r1[0]), a1 = __float_as_uint(r1[1]);
+  const f32x2 mm = {__uint_as_float(a0 & 0xFFFF0000u), __uint_as_float(a1 & 0xFFFF0000u)};
+  const f32x2 r2 = r1 - mm;
+  vh[qo] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+  vm[qo] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+  vl[qo] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+}
+
+// Product tile out[i,j] = sum_k A[i,k] B(k,j), interior tiles only (rows/cols multiples of the tile, (kend - kbeg) a
+// multiple of 16, 16-byte aligned A rows).  A is [rows, K] (k contiguous).  NN = false: B is [cols, K] (k contiguous,
+// 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
+// gathers 8 k of ONE column with dword loads (a wave-load = 256 contiguous bytes of one k-row).
+// Pro: transform of the staged fp32 values (centring), NT only.
+template <int TM, int TN, bool NN, class Pro>
+struct GemmTileX6 {
+  static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
+  static constexpr int CA = TM * 4 / kThreads, CB = TN * 4 / kThreads;  // 4-k quads staged per thread per tile
+  static_assert(CA >= 1 && CB >= 1, "tile too small");
+  using Smem = X6Smem<TM, TN>;
+  f32x16 acc[MI][NI];
+
+  // Ab / Bb: this member's operands, bytesA / bytesB their sizes (< 4 GiB: offsets are 32-bit)
+  __device__ __forceinline__ void run(Smem& sm, const float* Ab, unsigned bytesA, int lda, const float* Bb,
+                                      unsigned bytesB, int ldb, int row0, int col0, int kbeg, int kend, Pro& pro) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    f32x16 loc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // staging map: four consecutive lanes cover the 64-byte k-tile segment of one row (one wave-load = 16 whole
+    // segments); thread t stages quad kq = t & 3 of rows (t >> 2) + 64 i.  Buffer loads: the operand's base sits in
+    // a resource descriptor, the tile/k position in a scalar byte offset, the thread's place in ONE 32-bit VGPR
+    // offset per quad - no 64-bit address arithmetic in the loop.
+    const int kq = t & 3, srow = t >> 2;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, (int)bytesB, 0x00020000);
+    const unsigned sA0 = ((unsigned)row0 * lda + kbeg) * 4u;
+    const unsigned sB0 = NN ? ((unsigned)kbeg * ldb + col0) * 4u : ((unsigned)col0 * ldb + kbeg) * 4u;
+    unsigned aoff[CA], bgoff[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * 4u;
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+      bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) * 4u;
+    const int ntiles = (kend - kbeg) / kX6BK;
+    if (ntiles <= 0) return;
+
+    f32x4 ra[2][CA], rb[2][CB];  // two register sets: tiles t+1 and t+2 in flight
+    auto gload_a = [&](auto SET, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(SET)::value;
+      const unsigned so = sA0 + (unsigned)kt * (kX6BK * 4u);
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[i], (int)so, 0));
+    };
+    auto gload_b = [&](auto SET, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(SET)::value;
+      pro.prefetch(SET, kbeg + kt * kX6BK + 4 * kq);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        if (NN) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rsB, (int)bgoff[i], (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * 4u), 0));
+        } else {
+          rb[S][i] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[i], (int)(sB0 + (unsigned)kt * (kX6BK * 4u)), 0));
+        }
+      }
+    };
+    // bf16 offsets of this thread's quads in a plane
+    const int soff = srow * kX6LD + 4 * kq;
+    int boff[CB];
+#pragma unroll
+    for (int i = 0; i < CB; ++i) boff[i] = NN ? (t & 127) * kX6LD + 8 * (t >> 7) + 4 * i : soff + 64 * i * kX6LD;
+    auto stage_a = [&](auto SET, int st) __attribute__((always_inline)) {   // split + LDS write of the A quads
+      constexpr int S = decltype(SET)::value;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        u32x2 p[3];
+        pro.stageA(SET, ra[S][i], i);
+        split2(ra[S][i], 0, p[0], p[1], p[2], 0);
+        split2(ra[S][i], 2, p[0], p[1], p[2], 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
+      }
+    };
+    auto stage_b = [&](auto SET, int st) __attribute__((always_inline)) {
+      constexpr int S = decltype(SET)::value;
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        u32x2 p[3];
+        pro.stageB(SET, rb[S][i], i);
+        split2(rb[S][i], 0, p[0], p[1], p[2], 0);
+        split2(rb[S][i], 2, p[0], p[1], p[2], 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][boff[i]]) = p[q];
+      }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    gload_a(S0{}, 0);
+    gload_b(S0{}, 0);
+    if (ntiles > 1) { gload_a(S1{}, 1); gload_b(S1{}, 1); }
+    stage_a(S0{}, 0);
+    stage_b(S0{}, 0);
+    if (ntiles > 2) { gload_a(S0{}, 2); gload_b(S0{}, 2); }
+    __syncthreads();
+
+    // one k-tile: the 24 MFMAs of tile kt (LDS stage kt & 1), with the split + LDS write of tile kt+1 (register set
+    // NSET) and the global loads of tile kt+3 spread one piece per MFMA gap (a piece = 10 VALU, three ds_write_b64
+    // or the loads of one operand: about one 32-cycle MFMA).  FIRST: the local chain starts from zero.  GUARD: tail tiles, where
+    // tile kt+1 / kt+3 may not exist; the steady-state instance has no branch inside.
+    static_assert(TM == 128 && TN == 128 && CA == 2 && CB == 2 && MI == 2 && NI == 2, "schedule written for the 128x128 tile");
+    auto iter = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(NSET)::value;
+      constexpr bool G = decltype(GUARD)::value;
+      const int st = kt & 1;
+      const bool more = !G || kt + 1 < ntiles;
+      const bool load = !G || kt + 3 < ntiles;
+      // fragments: six 8-register groups (A/B x h/m/l) in FOUR register slots - each group is read one product
+      // group (4 MFMAs) before its first use, into the slot of a group whose last MFMA has issued:
+      //   products  lh hh mh mm hm hl ;  top: Al Bh Ah | gap 0: Am | gap 4: Bm (slot of Al) | gap 12: Bl (slot of Bh)
+      bf16x8 fa[MI][3], fb[NI][3];
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
+      auto lda_ = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+      };
+      auto ldb_ = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+      };
+      lda_(2);
+      ldb_(0);
+      lda_(0);
+      __builtin_amdgcn_sched_barrier(0);
+      u32x2 qv[3];
+#pragma unroll
+      for (int n = 0; n < 24; ++n) {
+        const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
+        {
+          f32x16 c = loc[i][j];
+          if (decltype(FIRST)::value && e == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c[q] = 0.f;
+          }
+          loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // gaps: 0 Am | 1-3 A quad 0 | 4 Bm | 5-7 A quad 1 | 8 A loads | 9-11 B quad 0 | 12 Bl | 13-15 B quad 1 | 16 B loads
+        if (n == 0) lda_(1);
+        else if (n == 4) ldb_(1);
+        else if (n == 12) ldb_(2);
+        else if (n == 8) { if (load) gload_a(NSET, kt + 3); }
+        else if (n == 16) { if (load) gload_b(NSET, kt + 3); }
+        else if (n < 16) {
+          const bool isA = n < 8;
+          const int quad = (n >> 2) & 1, step = (n & 3) - 1;
+          f32x4& src = isA ? ra[S][quad] : rb[S][quad];
+          if (more) {
+            if (step == 0) {
+              if (isA) pro.stageA(NSET, src, quad); else pro.stageB(NSET, src, quad);
+              split2(src, 0, qv[0], qv[1], qv[2], 0);
+            } else if (step == 1) {
+              split2(src, 2, qv[0], qv[1], qv[2], 1);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q];
+                else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    auto fold = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] += loc[i][j];
+    };
+    std::true_type T;
+    std::false_type F;
+    int kt = 0;
+    for (; kt + 7 <= ntiles; kt += 4) {   // steady state: tiles kt .. kt+3 all have a tile kt+3 behind them
+      iter(T, S1{}, F, kt);
+      iter(F, S0{}, F, kt + 1);
+      iter(F, S1{}, F, kt + 2);
+      iter(F, S0{}, F, kt + 3);
+      fold();
+    }
+    while (kt < ntiles) {
+      iter(T, S1{}, T, kt++);
+      if (kt < ntiles) iter(F, S0{}, T, kt++);
+      if (kt < ntiles) iter(F, S1{}, T, kt++);
+      if (kt < ntiles) iter(F, S0{}, T, kt++);
+      fold();
+    }
+  }
+
+  template <class Fn>
+  __device__ __forceinline__ void for_each(Fn&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          f(wr * WM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, wc * WN + j * 32 + l31, acc[i][j][q]);
+  }
+};
+
+struct NoPrologueX6 {
+  template <class S> __device__ __forceinline__ void prefetch(S, int) {}
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4&, int) {}
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4&, int) {}
+};
+
+}  // namespace hecka

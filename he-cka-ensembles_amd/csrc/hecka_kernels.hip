@@ -7,6 +7,7 @@
 
 #include "../../include/hecka.h"
 #include "gemm_mfma.hpp"
+#include "gemm_bf16x6.hpp"
 
 namespace hecka {
 
@@ -155,6 +156,85 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_kernel(GemmOperands g
   });
 }
 
+// Workgroup -> (member, tile).  Workgroup w runs on XCD w % 8 and each XCD has its own L2: with M % 8 == 0 all
+// tiles of a member go to ONE XCD, back to back, so the member's panels are read from HBM once and shared through
+// that L2 (otherwise every XCD streams every member: measured 15 % slower at P = 8192).
+__device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& tl) {
+  const int w = blockIdx.x;
+  if (xcd_map) {
+    const int slot = w >> 3;
+    m = (slot / per) * 8 + (w & 7);
+    tl = slot % per;
+  } else {
+    m = w / per;
+    tl = w % per;
+  }
+}
+
+// bf16x6 variant of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands split
+// into three bf16 terms on the way into LDS (gemm_bf16x6.hpp).
+struct CenterProX6 {
+  const float* sbar;
+  f32x4 s4[2];            // means of the k-quad this thread stages, per register set
+  f32x4 cav[2], cbv[2];   // per-lane partial dots (vector accumulators: two v_pk_fma_f32 per quad)
+  template <class S> __device__ __forceinline__ void prefetch(S, int k) {
+    s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
+  }
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int i) {
+    const f32x4 s = s4[S::value];
+    v -= s;
+    cav[i] += v * s;
+  }
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int i) {
+    const f32x4 s = s4[S::value];
+    v -= s;
+    cbv[i] += v * s;
+  }
+};
+
+__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
+                                                                     const float* __restrict__ sbar,
+                                                                     float* __restrict__ C, float* __restrict__ cvec,
+                                                                     int B, int P, int ntile, int xcd_map) {
+  using Tile = GemmTileX6<128, 128, false, CenterProX6>;
+  __shared__ typename Tile::Smem sm;
+  __shared__ float cA[128], cB[128];
+  int m, rem;
+  member_tile(ntile * (ntile + 1) / 2, xcd_map, m, rem);
+  int I = 0;
+  while (rem >= ntile - I) {
+    rem -= ntile - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const float* Xm = X + (size_t)m * B * P;
+  CenterProX6 pro;
+  pro.sbar = sbar + (size_t)m * P;
+  pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Tile tile;
+  tile.run(sm, Xm, (unsigned)B * P * 4u, P, Xm, (unsigned)B * P * 4u, P, I * 128, J * 128, 0, P, pro);
+  // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = pro.cav[i][0] + pro.cav[i][1] + pro.cav[i][2] + pro.cav[i][3];
+    float b = pro.cbv[i][0] + pro.cbv[i][1] + pro.cbv[i][2] + pro.cbv[i][3];
+    a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+    a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+    if ((threadIdx.x & 3) == 0) {
+      cA[(threadIdx.x >> 2) + 64 * i] = a;
+      cB[(threadIdx.x >> 2) + 64 * i] = b;
+    }
+  }
+  __syncthreads();
+  float* Cm = C + (size_t)m * B * B;
+  const int row0 = I * 128, col0 = J * 128;
+  if (I == J && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
+  tile.for_each([&](int lr, int lc, float v) {
+    Cm[(size_t)(row0 + lr) * B + col0 + lc] = v + cB[lc];
+    if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v + cA[lr];
+  });
+}
+
 // ------------------------------------------------------------------------------------------
 // (3) pairwise S = Ca Cb^T, split-K partials + fixed-order reduction.  HBM-bound: reads C once.
 // ------------------------------------------------------------------------------------------
@@ -258,6 +338,24 @@ __global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, f
     const int row = ti * 128 + lr, col = tj * 128 + lc;
     if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = v;
   });
+}
+
+// bf16x6 variant of dX = W X for interior shapes (B % 128 == 0, P % 128 == 0).  Tiles of one member that share an
+// X column panel are adjacent (ti fastest), all on one XCD.
+__global__ __launch_bounds__(kThreads, 2) void gram_bwd_x6_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                                  float* __restrict__ dX, int B, int P, int tilesM,
+                                                                  int tilesN, int xcd_map) {
+  using Tile = GemmTileX6<128, 128, true, NoPrologueX6>;
+  __shared__ typename Tile::Smem sm;
+  int m, tl;
+  member_tile(tilesM * tilesN, xcd_map, m, tl);
+  const int ti = tl % tilesM, tj = tl / tilesM;
+  NoPrologueX6 pro;
+  Tile tile;
+  tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, X + (size_t)m * B * P, (unsigned)B * P * 4u, P, ti * 128,
+           tj * 128, 0, B, pro);
+  float* out = dX + (size_t)m * B * P;
+  tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * 128 + lr) * P + tj * 128 + lc] = v; });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,7 +694,15 @@ using namespace hecka;
 
 extern "C" {
 
-int hecka_version(void) { return 1; }
+int hecka_version(void) { return 2; }
+
+static int g_gemm_mode = 0;
+int hecka_set_gemm_mode(int mode) {
+  if (mode != HECKA_GEMM_AUTO && mode != HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "set_gemm_mode: unknown mode%s");
+  g_gemm_mode = mode;
+  return HECKA_OK;
+}
+int hecka_get_gemm_mode(void) { return g_gemm_mode; }
 const char* hecka_last_error(void) { return g_err; }
 
 int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream) {
@@ -632,7 +738,12 @@ int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P
   const int ntile = (B + T - 1) / T;
   dim3 grid(ntile * (ntile + 1) / 2, M);
   const bool full = vec && (B % T == 0) && (P % kBK == 0);
-  if (full)
+  const long long nwg = (long long)grid.x * M;
+  if (g_gemm_mode == HECKA_GEMM_AUTO && vec && B % T == 0 && P % kX6BK == 0 && nwg < (1ll << 31) &&
+      (long long)B * P < (1ll << 29))
+    hipLaunchKernelGGL(gram_center_x6_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, C, cvec, B, P, ntile,
+                       (int)(M % 8 == 0));
+  else if (full)
     hipLaunchKernelGGL((gram_center_kernel<128, true, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
   else if (vec)
     hipLaunchKernelGGL((gram_center_kernel<128, true, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
@@ -864,7 +975,12 @@ int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, floa
   dim3 grid(tilesM * tilesN, M);
   hipStream_t st = (hipStream_t)stream;
   const bool full = vec && (B % 128 == 0) && (P % 128 == 0);
-  if (full)
+  const long long nwg = (long long)grid.x * M;
+  if (g_gemm_mode == HECKA_GEMM_AUTO && full && nwg < (1ll << 31) && (long long)B * P < (1ll << 29) &&
+      (long long)B * B < (1ll << 29))
+    hipLaunchKernelGGL(gram_bwd_x6_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, dX, B, P, tilesM, tilesN,
+                       (int)(M % 8 == 0));
+  else if (full)
     hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   else if (vec)
     hipLaunchKernelGGL((gram_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);

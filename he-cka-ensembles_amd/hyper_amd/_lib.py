@@ -15,6 +15,8 @@ _vp, _i, _ll, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes
 SIGNATURES = {
     'hecka_version': (_i, []),
     'hecka_last_error': (ctypes.c_char_p, []),
+    'hecka_set_gemm_mode': (_i, [_i]),
+    'hecka_get_gemm_mode': (_i, []),
     'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'hecka_gram_center_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),

@@ -30,6 +30,18 @@ extern "C" {
 int hecka_version(void);
 const char* hecka_last_error(void);
 
+/* Arithmetic of the two large GEMMs (hecka_gram_center_f32, hecka_gram_bwd_f32).  No counterpart in the reference
+ * (torch.bmm picks its own algorithm); a process-wide tuning knob.
+ *   HECKA_GEMM_AUTO (default): interior shapes (B % 128 == 0, P % 16 == 0 resp. P % 128 == 0) run on the bf16
+ *     matrix cores with every fp32 operand split exactly into three bf16 terms and six products per a*b, partial
+ *     sums folded with round-to-nearest fp32 adds - measured error <= 7e-7 of sum|a.b| at K = 8192, smaller than
+ *     the fp32-MFMA path's 2.5e-6; other shapes use fp32 MFMA.
+ *   HECKA_GEMM_FP32: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
+#define HECKA_GEMM_AUTO 0
+#define HECKA_GEMM_FP32 1
+int hecka_set_gemm_mode(int mode);
+int hecka_get_gemm_mode(void);
+
 /* Column mean of each member's features: sbar[m,p] = (1/B) sum_b X[m,b,p].
  * First half of the fused replacement of center_gram (hyper/diversity/kernels.py:335-345):
  * C = K - rowmean(K) == X (X - 1 sbar^T)^T, so the centring is applied to the features. */

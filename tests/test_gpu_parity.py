@@ -131,6 +131,36 @@ def test_bench_shape_properties():
     assert float((d12 - d1 - 2 * d2).abs().max()) <= 2e-5 * float(d12.abs().max())
 
 
+@pytest.mark.parametrize('M,B,P', [(8, 256, 80), (16, 128, 48), (3, 128, 144), (5, 384, 1024), (64, 512, 512)])
+def test_gemm_modes_against_fp64(M, B, P):
+    """Interior shapes run the two large GEMMs on the bf16 matrix cores with exactly split fp32 operands
+    (HECKA_GEMM_AUTO); HECKA_GEMM_FP32 forces fp32 MFMA.  Both against fp64 torch on the GPU, the bf16x6
+    path to the SAME tolerance as the fp32 one (2e-6 of the largest entry for the Gram, 1e-5 for dX)."""
+    from hyper_amd import ops, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + B + P)
+    X = (torch.randn(M, B, P, generator=g) ** 3 + 0.25).to(dev)     # skewed, non-zero mean
+    Xd = X.double()
+    K = Xd @ Xd.transpose(1, 2)
+    Cref = K - K.mean(2, keepdim=True)
+    A = torch.randn(M, M, generator=g).to(dev)
+    dC = torch.einsum('ij,jab->iab', A.double(), Cref)
+    Wd = (dC + dC.transpose(1, 2)) * (1 - torch.eye(B, dtype=torch.float64, device=dev))
+    dref = Wd @ Xd
+    L = _lib.lib()
+    try:
+        for mode in (0, 1):
+            assert L.hecka_set_gemm_mode(mode) == 0
+            C, cvec = ops.centered_gram(X)
+            assert float((C.double() - Cref).abs().max() / Cref.abs().max()) <= 2e-6, mode
+            cref = ((Xd - Xd.mean(1, keepdim=True)) * Xd.mean(1, keepdim=True)).sum(2)
+            assert float((cvec.double() - cref).abs().max() / cref.abs().max()) <= 1e-5, mode
+            dX = ops.gram_backward(A, C, cvec, X, True)
+            assert float((dX.double() - dref).abs().max() / dref.abs().max()) <= 1e-5, mode
+    finally:
+        L.hecka_set_gemm_mode(0)
+
+
 @pytest.mark.parametrize('P,style', [(512, 'randn'), (2048, 'correlated')])
 def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
     """Full bench member/sample counts (M=64, B=512) against the oracle evaluated in fp64 with stock

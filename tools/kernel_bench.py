@@ -17,6 +17,7 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 X = torch.randn(M, B, P, device=dev)
 L = _lib.lib()
+L.hecka_set_gemm_mode(int(os.environ.get('HECKA_GEMM_MODE', '0')))
 st = torch.cuda.current_stream().cuda_stream
 p = lambda t: t.data_ptr()
 sbar = torch.empty(M, P, device=dev)
