@@ -31,6 +31,7 @@ CFG = {'name': 'model_layers',
                         'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}},
        'layer_weighting': {'name': 'uniform'}}
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
@@ -127,6 +128,14 @@ def main():
         kms = sum(a.elapsed_time(b) for a, b, _ in prof['gram_bwd'])
         kfl = sum(fl for _, _, fl in prof['gram_bwd'])      # rank 0's launches (M/world members each)
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        from hyper_amd import _lib
+        if _lib.lib().hecka_get_gemm_mode() == 0:
+            # interior shapes: every fp32 multiply is six bf16 MFMA products (gemm_bf16x6.hpp), so the MFMA roof
+            # for ALGORITHMIC fp32 flops is the dense bf16 peak / 6
+            kname = 'gram_bwd_x6_kernel (dX = W X; fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply)'
+            peak, hw = PEAK_BF16_MATRIX_TFLOPS / 6.0, {'hw_bf16_tflops': ach * 6.0, 'hw_bf16_peak': PEAK_BF16_MATRIX_TFLOPS}
+        else:
+            kname, peak, hw = 'gram_bwd_kernel (dX = W X, fp32 MFMA)', PEAK_F32_MATRIX_TFLOPS, {}
         flops_eval = sum(4.0 * M * B * B * p + 4.0 * M * M * B * B for p in DIMS)
         out = {
             'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
@@ -136,9 +145,8 @@ def main():
                        'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
                                    'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
                        'loss': float(loss.item()), 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},
-            'roofline': {'bound': 'mfma', 'kernel': 'gram_bwd_kernel (dX = W X, fp32 MFMA)', 'achieved': ach,
-                         'peak': PEAK_F32_MATRIX_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MATRIX_TFLOPS,
-                         'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': None},
+            'roofline': dict({'bound': 'mfma', 'kernel': kname, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                              'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': None}, **hw),
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

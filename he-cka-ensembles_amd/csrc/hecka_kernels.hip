@@ -447,7 +447,10 @@ __device__ __forceinline__ void head_value(const HeadCfg& c, double cosv, double
   dval_dcos = d;
 }
 
-constexpr int kHeadThreads = 1024;  // one workgroup, 16 waves: the head is latency-bound fp64 transcendental work
+// Workgroups of 256 threads: the head runs while other layers' GEMM grids own the machine (two 256-VGPR GEMM
+// workgroups fill a CU's register file), so a head workgroup must fit the slot ONE finished GEMM workgroup frees -
+// a 1024-thread workgroup waited ~400 us for a whole free CU.
+constexpr int kHeadThreads = 256;
 __device__ __forceinline__ double block_sum_head(double v, double* red) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -460,6 +463,7 @@ __device__ __forceinline__ double block_sum_head(double v, double* red) {
   return t;
 }
 
+// forward: one workgroup (the sum over all pairs is taken in a fixed order: deterministic)
 __global__ __launch_bounds__(kHeadThreads) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
                                                        int Ma, int Mb, HeadCfg c, float* __restrict__ val,
                                                        float* __restrict__ sum_out, double scale) {
@@ -477,53 +481,48 @@ __global__ __launch_bounds__(kHeadThreads) void head_fwd_kernel(const float* __r
   if (sum_out && threadIdx.x == 0) *sum_out = (float)(tot * scale);
 }
 
+// backward: rows are independent - one wave per row i, four rows per workgroup, no LDS.
 // upstream dLoss/dvalue_ij = (up_mat ? up_mat[i,j] : 1) * (up_scalar ? *up_scalar : 1) * scale.
 // A matrix upstream needs the transposed entry too, so it requires Ma == Mb (single GPU).
+//   Gs_ij = G_ij (+ G_ji)   (cos is symmetric, so G_ji differs from G_ij only through up_mat)
+//   A_ij = Gs_ij/(d_i d_j);  A_ii = Gs_ii eps/d_i^3 - (sum_{j!=i} Gs_ij S_ij/d_j)/(n_i d_i^2)
 __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
                                                        int Ma, int Mb, HeadCfg c, const float* __restrict__ up_mat,
                                                        const float* __restrict__ up_scalar, double scale,
                                                        float* __restrict__ A) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * (kHeadThreads / 64) + wave;
+  if (i >= Ma) return;
   const double us = (up_scalar ? (double)*up_scalar : 1.0) * scale;
-  // phase 1: Gs_ij = G_ij (+ G_ji)   (cos is symmetric, so G_ji differs from G_ij only through up_mat)
-  for (int e = threadIdx.x; e < Ma * Mb; e += kHeadThreads) {
-    const int i = e / Mb, j = e - i * Mb;
-    const int gi = c.row_offset + i;
+  const int gi = c.row_offset + i;
+  const double ni = sqrt((double)nsq[gi]), di = ni + c.eps;
+  double vg = 0.0, gii = 0.0;
+  for (int j = lane; j < Mb; j += 64) {
+    const size_t e = (size_t)i * Mb + j;
+    const double dj = sqrt((double)nsq[j]) + c.eps;
+    const double sij = (double)S[e];
     double g = 0.0;
     if (!(c.remove_diag && j == gi)) {
-      const double di = sqrt((double)nsq[gi]) + c.eps, dj = sqrt((double)nsq[j]) + c.eps;
       double v, dv;
-      head_value(c, (double)S[e] / (di * dj), v, dv);
-      const double uij = (up_mat ? (double)up_mat[e] : 1.0) * us;
-      g = uij * dv;
-      if (!c.detach_right) {
-        const double uji = (up_mat ? (double)up_mat[(size_t)j * Mb + gi] : 1.0) * us;
-        g += uji * dv;
-      }
+      head_value(c, sij / (di * dj), v, dv);
+      g = (up_mat ? (double)up_mat[e] : 1.0) * us * dv;
+      if (!c.detach_right) g += (up_mat ? (double)up_mat[(size_t)j * Mb + gi] : 1.0) * us * dv;
     }
-    A[e] = (float)g;
+    if (j != gi) {
+      vg += g * sij / dj;
+      A[e] = (float)(g / (di * dj));
+    } else {
+      gii = g;
+    }
   }
-  __syncthreads();
-  // phase 2: one wave per row: A_ij = Gs_ij/(d_i d_j);  A_ii = Gs_ii eps/d_i^3 - (sum_{j!=i} Gs_ij S_ij/d_j)/(n_i d_i^2)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < Ma; i += kHeadThreads / 64) {
-    const int gi = c.row_offset + i;
-    const double ni = sqrt((double)nsq[gi]), di = ni + c.eps;
-    double vg = 0.0;
-    for (int j = lane; j < Mb; j += 64) {
-      const double dj = sqrt((double)nsq[j]) + c.eps;
-      const double g = (double)A[(size_t)i * Mb + j];
-      if (j != gi) {
-        vg += g * (double)S[(size_t)i * Mb + j] / dj;
-        A[(size_t)i * Mb + j] = (float)(g / (di * dj));
-      }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vg += __shfl_xor(vg, o);
-    if (lane == 0) {
-      const double gii = (double)A[(size_t)i * Mb + gi];
-      const double self = ni > 0.0 ? vg / (ni * di * di) : 0.0;
-      A[(size_t)i * Mb + gi] = (float)(gii * c.eps / (di * di * di) - self);
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    vg += __shfl_xor(vg, o);
+    gii += __shfl_xor(gii, o);   // only the lane holding j == gi contributed
+  }
+  if (lane == 0 && gi < Mb) {
+    const double self = ni > 0.0 ? vg / (ni * di * di) : 0.0;
+    A[(size_t)i * Mb + gi] = (float)(gii * c.eps / (di * di * di) - self);
   }
 }
 
@@ -894,7 +893,7 @@ int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   if (up_mat && Ma != Mb) return fail(HECKA_EINVAL, "head_bwd: a matrix upstream needs Ma == Mb%s");
   HeadCfg c;
   if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((Ma + kHeadThreads / 64 - 1) / (kHeadThreads / 64)), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
                      scale, A);
   return check_launch("head_bwd");
 }

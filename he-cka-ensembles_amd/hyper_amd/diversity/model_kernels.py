@@ -15,6 +15,8 @@ are outside the hot path and are not built."""
 import copy
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -254,7 +256,9 @@ class ModelLayersKernel(BaseModelKernel):
     # and its small [M,M] kernels overlap with another layer's MFMA work.  Autograd replays every node on
     # the stream it ran on in forward, so the backward overlaps the same way.  0/1 = everything in order on
     # the current stream.
-    num_streams = 4
+    num_streams = int(os.environ.get('HECKA_LAYER_STREAMS', '4'))
+    # (stream priorities were tried: with more streams than hardware queues a high-priority stream starved the rest
+    # - 0.6 evals/s - so all layer streams keep the default priority)
     _streams = {}
 
     def _side_streams(self, device, n):
@@ -284,15 +288,20 @@ class ModelLayersKernel(BaseModelKernel):
             streams = self._side_streams(flist[0].device, nstream)
             for st in streams:
                 st.wait_stream(main)
-            for index, feat in enumerate(flist):
-                st = streams[index % nstream]
+            # biggest layers first, each on the next stream: their long GEMM chains start early
+            order = sorted(range(total), key=lambda i: -flist[i][0].numel())
+            slot = {layer: k % nstream for k, layer in enumerate(order)}
+            values = [None] * total
+            for index in order:
+                feat = flist[index]
+                st = streams[slot[index]]
                 with torch.cuda.stream(st):
                     v = self._layer_value(kerns[index], params, feat, pred, layer_track[index])
                     v.record_stream(main)
                     g = layer_track[index].get('gram')
                     if g is not None:
                         g.record_stream(main)
-                values.append(v)
+                values[index] = v
             for st in streams:
                 main.wait_stream(st)
         else:
