@@ -40,16 +40,15 @@ struct X6Smem {
 // two of the four floats of v (elements q0, q0+1) -> one packed dword per plane
 template <class V>
 __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& vl, int qo) {
-  const f32x2 x = {v[q0], v[q0 + 1]};
-  const unsigned x0 = __float_as_uint(x[0]), x1 = __float_as_uint(x[1]);
-  const f32x2 hh = {__uint_as_float(x0 & 0xFFFF0000u), __uint_as_float(x1 & 0xFFFF0000u)};
-  const f32x2 r1 = x - hh;
-  const unsigned a0 = __float_as_uint(r1[0]), a1 = __float_as_uint(r1[1]);
-  const f32x2 mm = {__uint_as_float(a0 & 0xFFFF0000u), __uint_as_float(a1 & 0xFFFF0000u)};
-  const f32x2 r2 = r1 - mm;
-  vh[qo] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+  // plain (unpacked) f32 subtracts: packed-f32 VALU ops beside MFMAs cost several times their issue slot
+  const float x0 = v[q0], x1 = v[q0 + 1];
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(b1 & 0xFFFF0000u);   // exact
+  const unsigned a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
+  const float t0 = r0 - __uint_as_float(a0 & 0xFFFF0000u), t1 = r1 - __uint_as_float(a1 & 0xFFFF0000u);   // exact
+  vh[qo] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);   // high halves of (x1, x0)
   vm[qo] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-  vl[qo] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+  vl[qo] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
 }
 
 // Product tile out[i,j] = sum_k A[i,k] B(k,j), interior tiles only (rows/cols multiples of the tile, (kend - kbeg) a
@@ -237,7 +236,9 @@ struct GemmTileX6 {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] += loc[i][j];
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] += loc[i][j][q];   // v_add_f32, round to nearest
     };
     std::true_type T;
     std::false_type F;

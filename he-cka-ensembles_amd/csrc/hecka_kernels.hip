@@ -176,19 +176,25 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
 struct CenterProX6 {
   const float* sbar;
   f32x4 s4[2];            // means of the k-quad this thread stages, per register set
-  f32x4 cav[2], cbv[2];   // per-lane partial dots (vector accumulators: two v_pk_fma_f32 per quad)
+  f32x4 cav[2], cbv[2];   // per-lane partial dots, one accumulator per staged element
   template <class S> __device__ __forceinline__ void prefetch(S, int k) {
     s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
   }
   template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int i) {
     const f32x4 s = s4[S::value];
-    v -= s;
-    cav[i] += v * s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // element-wise on purpose (no packed f32 ops beside the MFMAs)
+      v[e] -= s[e];
+      cav[i][e] = fmaf(v[e], s[e], cav[i][e]);
+    }
   }
   template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int i) {
     const f32x4 s = s4[S::value];
-    v -= s;
-    cbv[i] += v * s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] -= s[e];
+      cbv[i][e] = fmaf(v[e], s[e], cbv[i][e]);
+    }
   }
 };
 

@@ -9,8 +9,10 @@
 using namespace hecka;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d line %d\n", (int)e_, __LINE__); exit(1); } } while (0)
 
+// bit 30 of P: every member reads member 0's data (L2-resident working set)
+__device__ __forceinline__ int P_alias_mod(int P) { return (P >> 30) & 1 ? 1 : 1 << 20; }
 template <bool XCDMAP>
-__global__ __launch_bounds__(kThreads, 2) void x6_kernel(const float* X, int B, int P, float* out) {
+__global__ __launch_bounds__(kThreads, 2) void x6_kernel(const float* X, int B, int P, float* out, unsigned long long* dbg) {
   using Tile = GemmTileX6<128, 128, false, NoPrologueX6>;
   __shared__ typename Tile::Smem sm;
   const int nt = B / 128;
@@ -21,10 +23,11 @@ __global__ __launch_bounds__(kThreads, 2) void x6_kernel(const float* X, int B, 
     tl = slot % per;
   }
   const int ti = tl / nt, tj = tl % nt;
-  const float* Xm = X + (size_t)m * B * P;
+  const float* Xm = X + (size_t)(m % P_alias_mod(P)) * B * (P & 0xFFFFFF);
   NoPrologueX6 pro;
   Tile tile;
-  tile.run(sm, Xm, (unsigned)B * P * 4u, P, Xm, (unsigned)B * P * 4u, P, ti * 128, tj * 128, 0, P, pro);
+  const int Pm = P & 0xFFFFFF;
+  tile.run(sm, Xm, (unsigned)B * Pm * 4u, Pm, Xm, (unsigned)B * Pm * 4u, Pm, ti * 128, tj * 128, 0, Pm, pro);
   float* o = out + (size_t)m * B * B;
   tile.for_each([&](int lr, int lc, float v) { o[(size_t)(ti * 128 + lr) * B + tj * 128 + lc] = v; });
 }
@@ -47,10 +50,13 @@ int main(int argc, char** argv) {
   srand(3);
   for (auto& v : h) { float u = (rand() % 20001) / 10000.f - 1.f; v = u * u * u + mean; }   // skewed, non-zero mean
   CK(hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  unsigned long long* dbg; CK(hipMalloc(&dbg, 8 * 32 * 8)); CK(hipMemset(dbg, 0, 8 * 32 * 8));
   GemmOperands g; g.A = X; g.B = X; g.strideA = g.strideB = (long long)B * P; g.lda = g.ldb = P; g.rowsA = g.colsB = B; g.K = P; g.kchunk = P;
   dim3 grid((B / 128) * (B / 128), M);
-  auto run_x6 = [&]() { hipLaunchKernelGGL(x6_kernel<false>, grid, dim3(kThreads), 0, 0, X, B, P, o1); };
-  auto run_x6l = [&]() { hipLaunchKernelGGL(x6_kernel<true>, grid, dim3(kThreads), 0, 0, X, B, P, o3); };
+  auto run_x6 = [&]() { hipLaunchKernelGGL(x6_kernel<false>, grid, dim3(kThreads), 0, 0, X, B, P, o1, dbg); };
+  const int alias = argc > 4 ? atoi(argv[4]) : 0;
+  const int dynlds = argc > 5 ? atoi(argv[5]) : 0;
+  auto run_x6l = [&]() { hipLaunchKernelGGL(x6_kernel<true>, grid, dim3(kThreads), dynlds, 0, X, B, P | (alias << 30), o3, dbg); };
   auto run_f32 = [&]() { hipLaunchKernelGGL(f32_kernel, grid, dim3(kThreads), 0, 0, g, o2); };
   run_x6(); run_f32(); run_x6l(); CK(hipDeviceSynchronize()); CK(hipGetLastError());
   // accuracy vs fp64 on a sample of entries of member 0 and M-1
@@ -74,6 +80,8 @@ int main(int argc, char** argv) {
   }
   printf("max |err| / sum|a.b|:  bf16x6 %.3e   fp32-mfma %.3e  bf16x6-local %.3e\n", e1, e2, e3);
   printf("mean err / sum|a.b|:   bf16x6 %.3e   fp32-mfma %.3e  bf16x6-local %.3e\n", b1 / 8000, b2 / 8000, b3 / 8000);
+  { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, x6_kernel<true>, kThreads, 0)); printf("x6 kernel: %d workgroups per CU\n", nb);
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f32_kernel, kThreads, 0)); printf("f32 kernel: %d workgroups per CU\n", nb); }
   hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
   const double fl = 2.0 * M * B * (double)B * P;
   for (int v = 0; v < 3; ++v) {
