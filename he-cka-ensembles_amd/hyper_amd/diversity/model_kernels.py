@@ -52,6 +52,21 @@ class BaseModelKernel(nn.Module):
         return config
 
 
+def host_scalar(owner, param):
+    """float(param) without a device round trip on every call: the value is read back once and cached against
+    the parameter's version counter and storage (in-place updates, load_state_dict and .to() all change one of
+    them).  A `float(p)` on a device parameter is a blocking copy; four of them per layer per evaluation
+    serialised the layer streams behind whatever GEMM grid owned the GPU."""
+    cache = owner.__dict__.setdefault('_host_scalars', {})
+    key = (id(param), param._version, param.data_ptr())
+    hit = cache.get(id(param))
+    if hit is None or hit[0] != key:
+        hit = (key, float(param.detach().cpu()))
+        cache[id(param)] = hit
+    return hit[1]
+
+
+
 @register_model_kernel('feature')
 class FeatureKernel(BaseModelKernel):
     """Batched Gram over tracked features [M,B,*].  `params` become fp32 0-dim Parameters under
@@ -87,7 +102,7 @@ class FeatureKernel(BaseModelKernel):
         if self.kernel == 'cossim' and not self.kwargs:
             return ops.GramSpec(ops.GRAM_COSSIM)
         if self.kernel == 'rbf' and set(self.kwargs) <= {'median'}:
-            return ops.GramSpec(ops.GRAM_RBF, float(self.params['param']), self.kwargs.get('median', True))
+            return ops.GramSpec(ops.GRAM_RBF, host_scalar(self, self.params['param']), self.kwargs.get('median', True))
         return None
 
     @staticmethod
@@ -181,7 +196,7 @@ class CKAModelKernel(_PairwiseHead):
     def _spec(self):
         if not (self.center and self.feature_kernel.fusable) or self._learnable():
             return None
-        return ops.HeadSpec(ops.HEAD_CKA, eps=float(self.eps), remove_diag=self.reduction == 'off_diag',
+        return ops.HeadSpec(ops.HEAD_CKA, eps=host_scalar(self, self.eps), remove_diag=self.reduction == 'off_diag',
                             detach_right=self.detach_right)
 
     def forward(self, params, feats, preds, track, layer=None):
@@ -220,7 +235,7 @@ class HEModelKernel(_PairwiseHead):
     def _spec(self):
         if not (self.center and self.feature_kernel.fusable) or self._learnable():
             return None
-        return ops.HeadSpec(ops.HEAD_HE, s=self.he_s, eps=float(self.eps), arc_eps=float(self.arc_eps),
+        return ops.HeadSpec(ops.HEAD_HE, s=self.he_s, eps=host_scalar(self, self.eps), arc_eps=host_scalar(self, self.arc_eps),
                             use_exp=self.use_exp, abs_vals=self.abs_vals, remove_diag=self.reduction == 'off_diag',
                             detach_right=self.detach_right)
 
