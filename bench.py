@@ -31,7 +31,7 @@ CFG = {'name': 'model_layers',
                         'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}},
        'layer_weighting': {'name': 'uniform'}}
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
@@ -81,8 +81,9 @@ def main():
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)
 
-    from hyper_amd import ops
+    from hyper_amd import ops, _lib as _hl
     from hyper_amd.diversity.model_kernels import build_model_kernel
+    _hl.lib().hecka_set_gemm_mode(int(os.environ.get('HECKA_GEMM_MODE', '0')))   # 0 auto (f16x3) | 2 bf16x6 | 1 fp32 MFMA
 
     if M % world:
         raise SystemExit('M=%d members do not shard over %d GPUs' % (M, world))
@@ -129,10 +130,14 @@ def main():
         kfl = sum(fl for _, _, fl in prof['gram_bwd'])      # rank 0's launches (M/world members each)
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         from hyper_amd import _lib
-        if _lib.lib().hecka_get_gemm_mode() == 0:
-            # interior shapes: every fp32 multiply is six bf16 MFMA products (gemm_bf16x6.hpp), so the MFMA roof
-            # for ALGORITHMIC fp32 flops is the dense bf16 peak / 6
-            kname = 'gram_bwd_x6_kernel (dX = W X; fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply)'
+        mode = _lib.lib().hecka_get_gemm_mode()
+        if mode == 0:
+            # interior shapes, maxima supplied: every fp32 multiply is THREE fp16 MFMA products (gemm_bf16x6.hpp,
+            # scheme f16x3), so the MFMA roof for ALGORITHMIC fp32 flops is the dense 16-bit peak / 3
+            kname = 'gram_bwd_x6_kernel<1> (dX = W X; fp32 operands split into 2 fp16 terms, 3 fp16 MFMA products per multiply)'
+            peak, hw = PEAK_BF16_MATRIX_TFLOPS / 3.0, {'hw_f16_tflops': ach * 3.0, 'hw_f16_peak': PEAK_BF16_MATRIX_TFLOPS}
+        elif mode == 2:
+            kname = 'gram_bwd_x6_kernel<0> (dX = W X; fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply)'
             peak, hw = PEAK_BF16_MATRIX_TFLOPS / 6.0, {'hw_bf16_tflops': ach * 6.0, 'hw_bf16_peak': PEAK_BF16_MATRIX_TFLOPS}
         else:
             kname, peak, hw = 'gram_bwd_kernel (dX = W X, fp32 MFMA)', PEAK_F32_MATRIX_TFLOPS, {}

@@ -31,11 +31,39 @@ constexpr int kX6BK = 16;
 constexpr int kX6LD = 24;   // bf16 per padded LDS row (48 B)
 constexpr int kX6Fold = 4;  // k-tiles per local accumulation chain
 
-template <int TM, int TN>
+// SCHEME 0 "bf16x6": three bf16 planes, six products.  SCHEME 1 "f16x3": x*2^e = h + l with two fp16 terms
+// (22 significand bits), three products hh + hl + lh; half the MFMA work and 2/3 of the LDS traffic, but the
+// operand must be pre-scaled into fp16 range by the caller's prologue (Pro::scaleA / scaleB, powers of two).
+template <int TM, int TN, int NP>
 struct X6Smem {
-  alignas(16) unsigned short a[2][3][TM * kX6LD];
-  alignas(16) unsigned short b[2][3][TN * kX6LD];
+  alignas(16) unsigned short a[2][NP][TM * kX6LD];
+  alignas(16) unsigned short b[2][NP][TN * kX6LD];
 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// fp16 two-term split of two floats (already scaled into range): h = rne16(x), l = rne16(x - h); x - h is exact in
+// fp32 and |x - h - l| <= 2^-24 |x| (v_cvt_pk_f16_f32 rounds to nearest: no truncation bias)
+template <class V>
+__device__ __forceinline__ void split2h(const f32x4& v, int q0, V& vh, V& vl, int qo) {
+  const f32x2 x = {v[q0], v[q0 + 1]};
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  const f32x2 r = {x[0] - (float)h[0], x[1] - (float)h[1]};
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  vh[qo] = __builtin_bit_cast(unsigned, h);
+  vl[qo] = __builtin_bit_cast(unsigned, l);
+}
+
+// power-of-two scale s with bound * s <= 2^headroom (exact to apply and to undo); 1 for zero / non-finite bounds
+__device__ __forceinline__ float pow2_scale(float bound, int headroom) {
+  const unsigned b = __float_as_uint(bound) & 0x7FFFFFFFu;
+  const int be = (int)(b >> 23);
+  if (be == 0 || be == 255) return 1.0f;
+  int k = headroom - (be - 126);      // bound < 2^(be-126)
+  k = k < -60 ? -60 : (k > 60 ? 60 : k);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
 
 // two of the four floats of v (elements q0, q0+1) -> one packed dword per plane
 template <class V>
@@ -56,12 +84,13 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
 // 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
 // gathers 8 k of ONE column with dword loads (a wave-load = 256 contiguous bytes of one k-row).
 // Pro: transform of the staged fp32 values (centring), NT only.
-template <int TM, int TN, bool NN, class Pro>
+template <int TM, int TN, bool NN, class Pro, int SCHEME = 0>
 struct GemmTileX6 {
+  static constexpr int NP = SCHEME == 1 ? 2 : 3;
   static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
   static constexpr int CA = TM * 4 / kThreads, CB = TN * 4 / kThreads;  // 4-k quads staged per thread per tile
   static_assert(CA >= 1 && CB >= 1, "tile too small");
-  using Smem = X6Smem<TM, TN>;
+  using Smem = X6Smem<TM, TN, NP>;
   f32x16 acc[MI][NI];
 
   // Ab / Bb: this member's operands, bytesA / bytesB their sizes (< 4 GiB: offsets are 32-bit)
@@ -130,10 +159,15 @@ struct GemmTileX6 {
       for (int i = 0; i < CA; ++i) {
         u32x2 p[3];
         pro.stageA(SET, ra[S][i], i);
-        split2(ra[S][i], 0, p[0], p[1], p[2], 0);
-        split2(ra[S][i], 2, p[0], p[1], p[2], 1);
+        if (SCHEME == 1) {
+          split2h(ra[S][i], 0, p[0], p[1], 0);
+          split2h(ra[S][i], 2, p[0], p[1], 1);
+        } else {
+          split2(ra[S][i], 0, p[0], p[1], p[2], 0);
+          split2(ra[S][i], 2, p[0], p[1], p[2], 1);
+        }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
       }
     };
     auto stage_b = [&](auto SET, int st) __attribute__((always_inline)) {
@@ -142,10 +176,15 @@ struct GemmTileX6 {
       for (int i = 0; i < CB; ++i) {
         u32x2 p[3];
         pro.stageB(SET, rb[S][i], i);
-        split2(rb[S][i], 0, p[0], p[1], p[2], 0);
-        split2(rb[S][i], 2, p[0], p[1], p[2], 1);
+        if (SCHEME == 1) {
+          split2h(rb[S][i], 0, p[0], p[1], 0);
+          split2h(rb[S][i], 2, p[0], p[1], 1);
+        } else {
+          split2(rb[S][i], 0, p[0], p[1], p[2], 0);
+          split2(rb[S][i], 2, p[0], p[1], p[2], 1);
+        }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][boff[i]]) = p[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][boff[i]]) = p[q];
       }
     };
 
@@ -232,6 +271,64 @@ struct GemmTileX6 {
       }
       __syncthreads();
     };
+    // f16x3 k-tile: 12 MFMAs (hh, hl, lh on the four 32x32 tiles); all four fragment groups are read at the top;
+    // gaps: 0 A q0 split | 1 A q0 write | 2 A q1 split | 3 A q1 write | 4 A loads | 5-8 B likewise | 9 B loads
+    auto iter16 = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(NSET)::value;
+      constexpr bool G = decltype(GUARD)::value;
+      const int st = kt & 1;
+      const bool more = !G || kt + 1 < ntiles;
+      const bool load = !G || kt + 3 < ntiles;
+      f16x8 fa[MI][2], fb[NI][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fb[j][p] = *reinterpret_cast<const f16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int PA[3] = {0, 0, 1};
+      constexpr int PB[3] = {0, 1, 0};
+      u32x2 qv[2];
+#pragma unroll
+      for (int n = 0; n < 12; ++n) {
+        const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
+        {
+          f32x16 c = loc[i][j];
+          if (decltype(FIRST)::value && e == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c[q] = 0.f;
+          }
+          loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n == 4) { if (load) gload_a(NSET, kt + 3); }
+        else if (n == 9) { if (load) gload_b(NSET, kt + 3); }
+        else if (n < 9) {
+          const bool isA = n < 4;
+          const int r = isA ? n : n - 5, quad = r >> 1, step = r & 1;
+          f32x4& src = isA ? ra[S][quad] : rb[S][quad];
+          if (more) {
+            if (step == 0) {
+              if (isA) pro.stageA(NSET, src, quad); else pro.stageB(NSET, src, quad);
+              split2h(src, 0, qv[0], qv[1], 0);
+              split2h(src, 2, qv[0], qv[1], 1);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q];
+                else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
     auto fold = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -242,19 +339,23 @@ struct GemmTileX6 {
     };
     std::true_type T;
     std::false_type F;
+    auto step = [&](auto FIRST, auto NSET, auto GUARD, int kt_) __attribute__((always_inline)) {
+      if constexpr (SCHEME == 1) iter16(FIRST, NSET, GUARD, kt_);
+      else iter(FIRST, NSET, GUARD, kt_);
+    };
     int kt = 0;
     for (; kt + 7 <= ntiles; kt += 4) {   // steady state: tiles kt .. kt+3 all have a tile kt+3 behind them
-      iter(T, S1{}, F, kt);
-      iter(F, S0{}, F, kt + 1);
-      iter(F, S1{}, F, kt + 2);
-      iter(F, S0{}, F, kt + 3);
+      step(T, S1{}, F, kt);
+      step(F, S0{}, F, kt + 1);
+      step(F, S1{}, F, kt + 2);
+      step(F, S0{}, F, kt + 3);
       fold();
     }
     while (kt < ntiles) {
-      iter(T, S1{}, T, kt++);
-      if (kt < ntiles) iter(F, S0{}, T, kt++);
-      if (kt < ntiles) iter(F, S1{}, T, kt++);
-      if (kt < ntiles) iter(F, S0{}, T, kt++);
+      step(T, S1{}, T, kt++);
+      if (kt < ntiles) step(F, S0{}, T, kt++);
+      if (kt < ntiles) step(F, S1{}, T, kt++);
+      if (kt < ntiles) step(F, S0{}, T, kt++);
       fold();
     }
   }

@@ -259,6 +259,19 @@ struct GemmTile {
         for (int q = 0; q < 16; ++q)
           f(wr * WM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, wc * WN + j * 32 + l31, acc[i][j][q]);
   }
+  // Same, also passing the row-tile index i and the register index q (compile-time constants after unrolling).
+  template <class F>
+  __device__ __forceinline__ void for_each_idx(F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          f(i, q, wr * WM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, wc * WN + j * 32 + l31, acc[i][j][q]);
+  }
 };
 
 struct NoPrologue {

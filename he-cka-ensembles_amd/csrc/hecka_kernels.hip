@@ -31,10 +31,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // (1) column mean: sbar[m,p] = mean_b X[m,b,p].   HBM-bound: reads X once (4 B / element).
 // Block = 32 float4-columns x 16 row-slices (512 threads); grid (ceil(P/128), M).
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+// Optional side output xmax[m] = max |X[m]| (bit pattern of a non-negative float, combined with atomicMax; the
+// caller zeroes it): the fp16-split GEMMs scale their operands by a power of two derived from it.
+template <bool VEC, bool AMAX>
 __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
-                                                      float* __restrict__ sbar) {
+                                                      float* __restrict__ sbar, unsigned* __restrict__ xmax) {
   __shared__ f32x4 red[16][32];
+  float mx = 0.f;
   const int m = blockIdx.y;
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int p = (blockIdx.x * 32 + cx) * 4;
@@ -43,16 +46,36 @@ __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ 
   if (p < P) {
     if (VEC) {
 #pragma unroll 8
-      for (int b = ry; b < B; b += 16) acc += *reinterpret_cast<const f32x4*>(Xm + (size_t)b * P + p);
+      for (int b = ry; b < B; b += 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Xm + (size_t)b * P + p);
+        acc += v;
+        if (AMAX) mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+      }
     } else {
       for (int b = ry; b < B; b += 16)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (p + e < P) acc[e] += Xm[(size_t)b * P + p + e];
+          if (p + e < P) {
+            const float v = Xm[(size_t)b * P + p + e];
+            acc[e] += v;
+            if (AMAX) mx = fmaxf(mx, fabsf(v));
+          }
     }
+  }
+  __shared__ float wred[8];
+  if (AMAX) {   // one atomic per workgroup: thousands of same-address atomics serialise in L2
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mx;
   }
   red[ry][cx] = acc;
   __syncthreads();
+  if (AMAX && threadIdx.x == 0) {
+    float v = wred[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = fmaxf(v, wred[w]);
+    atomicMax(xmax + m, __float_as_uint(v));
+  }
   if (ry == 0 && p < P) {
     f32x4 s = red[0][cx];
 #pragma unroll
@@ -171,38 +194,38 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
   }
 }
 
-// bf16x6 variant of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands split
-// into three bf16 terms on the way into LDS (gemm_bf16x6.hpp).
+// Split-precision variants of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands
+// split on the way into LDS (gemm_bf16x6.hpp).  SCHEME 0: three bf16 terms.  SCHEME 1: two fp16 terms of the centred
+// value scaled by s = 2^k, k from xmax[m] so that |x - sbar| * s <= 2 xmax s <= 2^14; the epilogue undoes s^2.
+template <int SCHEME>
 struct CenterProX6 {
   const float* sbar;
+  float s;                // operand scale (SCHEME 1), 1 otherwise
   f32x4 s4[2];            // means of the k-quad this thread stages, per register set
-  f32x4 cav[2], cbv[2];   // per-lane partial dots, one accumulator per staged element
+  f32x4 cav[2], cbv[2];   // per-lane partial dots sbar . (x - sbar), one accumulator per staged element
   template <class S> __device__ __forceinline__ void prefetch(S, int k) {
     s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
   }
-  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int i) {
-    const f32x4 s = s4[S::value];
+  template <class S> __device__ __forceinline__ void stage(S, f32x4& v, f32x4& acc) {
+    const f32x4 m4 = s4[S::value];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {   // element-wise on purpose (no packed f32 ops beside the MFMAs)
-      v[e] -= s[e];
-      cav[i][e] = fmaf(v[e], s[e], cav[i][e]);
+      const float c = v[e] - m4[e];
+      acc[e] = fmaf(c, m4[e], acc[e]);
+      v[e] = SCHEME == 1 ? c * s : c;
     }
   }
-  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int i) {
-    const f32x4 s = s4[S::value];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] -= s[e];
-      cbv[i][e] = fmaf(v[e], s[e], cbv[i][e]);
-    }
-  }
+  template <class S> __device__ __forceinline__ void stageA(S t, f32x4& v, int i) { stage(t, v, cav[i]); }
+  template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
 
+template <int SCHEME>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
                                                                      const float* __restrict__ sbar,
+                                                                     const float* __restrict__ xmax,
                                                                      float* __restrict__ C, float* __restrict__ cvec,
                                                                      int B, int P, int ntile, int xcd_map) {
-  using Tile = GemmTileX6<128, 128, false, CenterProX6>;
+  using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME>;
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
   int m, rem;
@@ -214,9 +237,11 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float
   }
   const int J = I + rem;
   const float* Xm = X + (size_t)m * B * P;
-  CenterProX6 pro;
+  CenterProX6<SCHEME> pro;
   pro.sbar = sbar + (size_t)m * P;
+  pro.s = SCHEME == 1 ? pow2_scale(xmax[m], 13) : 1.0f;
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float unscale = SCHEME == 1 ? 1.0f / (pro.s * pro.s) : 1.0f;
   Tile tile;
   tile.run(sm, Xm, (unsigned)B * P * 4u, P, Xm, (unsigned)B * P * 4u, P, I * 128, J * 128, 0, P, pro);
   // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
@@ -236,6 +261,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float
   const int row0 = I * 128, col0 = J * 128;
   if (I == J && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
   tile.for_each([&](int lr, int lc, float v) {
+    if (SCHEME == 1) v *= unscale;
     Cm[(size_t)(row0 + lr) * B + col0 + lc] = v + cB[lc];
     if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v + cA[lr];
   });
@@ -327,6 +353,32 @@ __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, co
   });
 }
 
+// wmax[i] = max |W_i| over a row of n floats, for the fp16-split dX GEMM.  A separate pass right behind combine (W
+// is 4 M B^2 bytes, still in L2 / Infinity Cache): in-kernel atomics from combine's 8192 workgroups onto 64
+// addresses cost 10x the kernel.  Grid (chunks, rows); one atomic per workgroup; the caller zeroes wmax.
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ V, long long n, int chunks,
+                                                          unsigned* __restrict__ out) {
+  __shared__ float red[4];
+  const float* v = V + (size_t)blockIdx.y * n;
+  const long long per = ((n + chunks - 1) / chunks + 3) & ~3ll;
+  const long long beg = per * blockIdx.x, end = beg + per < n ? beg + per : n;
+  float mx = 0.f;
+  if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) {
+    for (long long e = beg + 4 * threadIdx.x; e + 3 < end; e += 4 * 256) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(v + e);
+      mx = fmaxf(fmaxf(fmaxf(mx, fabsf(q[0])), fmaxf(fabsf(q[1]), fabsf(q[2]))), fabsf(q[3]));
+    }
+    for (long long e = beg + ((end - beg) & ~3ll) + threadIdx.x; e < end; e += 256) mx = fmaxf(mx, fabsf(v[e]));
+  } else {
+    for (long long e = beg + threadIdx.x; e < end; e += 256) mx = fmaxf(mx, fabsf(v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out + blockIdx.y, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 // ------------------------------------------------------------------------------------------
 // (6) dX_m = W_m X_m.  MFMA-bound: 2*B*B*P flop per member.
 // ------------------------------------------------------------------------------------------
@@ -346,22 +398,49 @@ __global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, f
   });
 }
 
-// bf16x6 variant of dX = W X for interior shapes (B % 128 == 0, P % 128 == 0).  Tiles of one member that share an
-// X column panel are adjacent (ti fastest), all on one XCD.
+// Split-precision variants of dX = W X for interior shapes (B % 128 == 0, P % 128 == 0).  Tiles of one member that
+// share an X column panel are adjacent (ti fastest), all on one XCD.  SCHEME 1: W and X scaled by powers of two from
+// wmax[m] / xmax[m] into fp16 range, undone in the epilogue.
+template <int SCHEME>
+struct ScaleProX6 {
+  float sa, sb;
+  template <class S> __device__ __forceinline__ void prefetch(S, int) {}
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int) {
+    if (SCHEME == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= sa;
+    }
+  }
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int) {
+    if (SCHEME == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= sb;
+    }
+  }
+};
+
+template <int SCHEME>
 __global__ __launch_bounds__(kThreads, 2) void gram_bwd_x6_kernel(const float* __restrict__ W, const float* __restrict__ X,
+                                                                  const unsigned* __restrict__ wmax,
+                                                                  const float* __restrict__ xmax,
                                                                   float* __restrict__ dX, int B, int P, int tilesM,
                                                                   int tilesN, int xcd_map) {
-  using Tile = GemmTileX6<128, 128, true, NoPrologueX6>;
+  using Tile = GemmTileX6<128, 128, true, ScaleProX6<SCHEME>, SCHEME>;
   __shared__ typename Tile::Smem sm;
   int m, tl;
   member_tile(tilesM * tilesN, xcd_map, m, tl);
   const int ti = tl % tilesM, tj = tl / tilesM;
-  NoPrologueX6 pro;
+  ScaleProX6<SCHEME> pro;
+  pro.sa = SCHEME == 1 ? pow2_scale(__uint_as_float(wmax[m]), 14) : 1.0f;
+  pro.sb = SCHEME == 1 ? pow2_scale(xmax[m], 14) : 1.0f;
+  const float unscale = SCHEME == 1 ? 1.0f / (pro.sa * pro.sb) : 1.0f;
   Tile tile;
   tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, X + (size_t)m * B * P, (unsigned)B * P * 4u, P, ti * 128,
            tj * 128, 0, B, pro);
   float* out = dX + (size_t)m * B * P;
-  tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * 128 + lr) * P + tj * 128 + lc] = v; });
+  tile.for_each([&](int lr, int lc, float v) {
+    out[(size_t)(ti * 128 + lr) * P + tj * 128 + lc] = SCHEME == 1 ? v * unscale : v;
+  });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,18 +778,18 @@ using namespace hecka;
 
 extern "C" {
 
-int hecka_version(void) { return 2; }
+int hecka_version(void) { return 3; }
 
 static int g_gemm_mode = 0;
 int hecka_set_gemm_mode(int mode) {
-  if (mode != HECKA_GEMM_AUTO && mode != HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "set_gemm_mode: unknown mode%s");
+  if (mode != HECKA_GEMM_AUTO && mode != HECKA_GEMM_FP32 && mode != HECKA_GEMM_BF16X6) return fail(HECKA_EINVAL, "set_gemm_mode: unknown mode%s");
   g_gemm_mode = mode;
   return HECKA_OK;
 }
 int hecka_get_gemm_mode(void) { return g_gemm_mode; }
 const char* hecka_last_error(void) { return g_err; }
 
-int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream) {
+int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* xmax, void* stream) {
   clear_error();
   if (!X || !sbar) return fail(HECKA_EINVAL, "colmean: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "colmean: non-positive size%s");
@@ -718,15 +797,21 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* st
   const bool vec = (P % 4 == 0) && aligned16(X);
   dim3 grid((P + 127) / 128, M);
   hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL(colmean_kernel<true>, grid, dim3(512), 0, st, X, B, P, sbar);
+  unsigned* xm = reinterpret_cast<unsigned*>(xmax);
+  if (xm && hipMemsetAsync(xm, 0, (size_t)M * sizeof(unsigned), st) != hipSuccess) return check_launch("colmean (memset)");
+  if (vec && xm)
+    hipLaunchKernelGGL((colmean_kernel<true, true>), grid, dim3(512), 0, st, X, B, P, sbar, xm);
+  else if (vec)
+    hipLaunchKernelGGL((colmean_kernel<true, false>), grid, dim3(512), 0, st, X, B, P, sbar, xm);
+  else if (xm)
+    hipLaunchKernelGGL((colmean_kernel<false, true>), grid, dim3(512), 0, st, X, B, P, sbar, xm);
   else
-    hipLaunchKernelGGL(colmean_kernel<false>, grid, dim3(512), 0, st, X, B, P, sbar);
+    hipLaunchKernelGGL((colmean_kernel<false, false>), grid, dim3(512), 0, st, X, B, P, sbar, xm);
   return check_launch("colmean");
 }
 
-int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P, float* C, float* cvec,
-                          void* stream) {
+int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P, float* C,
+                          float* cvec, void* stream) {
   clear_error();
   if (!X || !sbar || !C || !cvec) return fail(HECKA_EINVAL, "gram_center: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_center: non-positive size%s");
@@ -744,10 +829,14 @@ int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P
   dim3 grid(ntile * (ntile + 1) / 2, M);
   const bool full = vec && (B % T == 0) && (P % kBK == 0);
   const long long nwg = (long long)grid.x * M;
-  if (g_gemm_mode == HECKA_GEMM_AUTO && vec && B % T == 0 && P % kX6BK == 0 && nwg < (1ll << 31) &&
-      (long long)B * P < (1ll << 29))
-    hipLaunchKernelGGL(gram_center_x6_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, C, cvec, B, P, ntile,
-                       (int)(M % 8 == 0));
+  const bool split_ok = g_gemm_mode != HECKA_GEMM_FP32 && vec && B % T == 0 && P % kX6BK == 0 && nwg < (1ll << 31) &&
+                        (long long)B * P < (1ll << 29);
+  if (split_ok && xmax && g_gemm_mode == HECKA_GEMM_AUTO)
+    hipLaunchKernelGGL(gram_center_x6_kernel<1>, dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, xmax, C, cvec, B, P,
+                       ntile, (int)(M % 8 == 0));
+  else if (split_ok)
+    hipLaunchKernelGGL(gram_center_x6_kernel<0>, dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, xmax, C, cvec, B, P,
+                       ntile, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_center_kernel<128, true, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
   else if (vec)
@@ -808,7 +897,7 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
 }
 
 static int combine_impl(const float* A, const float* C, const float* gamma, int Ma, int Mb, long long N, int B,
-                        int detach_diag, float* W, void* stream, int mode) {
+                        int detach_diag, float* W, float* wmax, void* stream, int mode) {
   clear_error();
   if (!A || !C || !W || (mode == 1 && !gamma)) return fail(HECKA_EINVAL, "combine: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || N <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
@@ -824,6 +913,8 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   dim3 grid(tilesM * tilesN);
   hipStream_t st = (hipStream_t)stream;
   const bool full = vec && (Ma % 64 == 0) && (N % 128 == 0) && (Mb % kBK == 0);
+  unsigned* wm = reinterpret_cast<unsigned*>(wmax);
+  if (wm && hipMemsetAsync(wm, 0, (size_t)Ma * sizeof(unsigned), st) != hipSuccess) return check_launch("combine (memset)");
 #define HECKA_COMBINE(V, MD, F) \
   hipLaunchKernelGGL((combine_kernel<V, MD, F>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN)
   if (mode == 1) {
@@ -836,17 +927,21 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
     else HECKA_COMBINE(false, 0, false);
   }
 #undef HECKA_COMBINE
+  if (wm) {
+    const int chunks = (int)(N >= (1 << 16) ? 16 : 1);
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, Ma), dim3(256), 0, st, W, N, chunks, wm);
+  }
   return check_launch("combine");
 }
 
 int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B, int detach_diag,
-                      float* W, void* stream) {
+                      float* W, float* wmax, void* stream) {
   if (B <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
-  return combine_impl(A, C, gamma, Ma, Mb, (long long)B * B, B, detach_diag, W, stream, 1);
+  return combine_impl(A, C, gamma, Ma, Mb, (long long)B * B, B, detach_diag, W, wmax, stream, 1);
 }
 
 int hecka_rowmix_f32(const float* A, const float* V, int Ma, int Mb, long long K, float* out, void* stream) {
-  return combine_impl(A, V, nullptr, Ma, Mb, K, 1, 0, out, stream, 0);
+  return combine_impl(A, V, nullptr, Ma, Mb, K, 1, 0, out, nullptr, stream, 0);
 }
 
 int hecka_center_rows_f32(const float* V, long long rows, int cols, float* out, float* mean, void* stream) {
@@ -964,7 +1059,8 @@ int hecka_bgemm_f32(const float* A, const float* Bm, float* C, int batch, int ro
   return check_launch("bgemm");
 }
 
-int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream) {
+int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,
+                       float* dX, void* stream) {
   clear_error();
   if (!W || !X || !dX) return fail(HECKA_EINVAL, "gram_bwd: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "gram_bwd: bad size%s");
@@ -981,10 +1077,15 @@ int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, floa
   hipStream_t st = (hipStream_t)stream;
   const bool full = vec && (B % 128 == 0) && (P % 128 == 0);
   const long long nwg = (long long)grid.x * M;
-  if (g_gemm_mode == HECKA_GEMM_AUTO && full && nwg < (1ll << 31) && (long long)B * P < (1ll << 29) &&
-      (long long)B * B < (1ll << 29))
-    hipLaunchKernelGGL(gram_bwd_x6_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, dX, B, P, tilesM, tilesN,
-                       (int)(M % 8 == 0));
+  const bool split_ok = g_gemm_mode != HECKA_GEMM_FP32 && full && nwg < (1ll << 31) && (long long)B * P < (1ll << 29) &&
+                        (long long)B * B < (1ll << 29);
+  const unsigned* wm = reinterpret_cast<const unsigned*>(wmax);
+  if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO)
+    hipLaunchKernelGGL(gram_bwd_x6_kernel<1>, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, tilesM,
+                       tilesN, (int)(M % 8 == 0));
+  else if (split_ok)
+    hipLaunchKernelGGL(gram_bwd_x6_kernel<0>, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, tilesM,
+                       tilesN, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   else if (vec)

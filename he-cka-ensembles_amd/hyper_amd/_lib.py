@@ -17,14 +17,14 @@ SIGNATURES = {
     'hecka_last_error': (ctypes.c_char_p, []),
     'hecka_set_gemm_mode': (_i, [_i]),
     'hecka_get_gemm_mode': (_i, []),
-    'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    'hecka_gram_center_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'hecka_gram_center_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
     'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
     'hecka_head_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp]),
     'hecka_head_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp, _vp]),
     'hecka_coef_gamma_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    'hecka_combine_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'hecka_combine_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_rowmix_f32': (_i, [_vp, _vp, _i, _i, _ll, _vp, _vp]),
     'hecka_center_rows_f32': (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     'hecka_symmetrize_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -32,7 +32,7 @@ SIGNATURES = {
     'hecka_gram_transform_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_transform_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'hecka_bgemm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, ctypes.c_float, _vp]),
-    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 

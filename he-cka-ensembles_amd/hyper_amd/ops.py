@@ -29,17 +29,20 @@ def _check_features(X):
         raise RuntimeError('expected features of shape [members, samples, features]')
 
 
-def centered_gram(X):
-    """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd."""
+def centered_gram(X, return_xmax=False):
+    """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd.
+    `return_xmax` adds xmax [M] = max |X[m]| (a by-product of the column-mean pass) for gram_backward: with it the
+    dX GEMM may use the fp16-split arithmetic (include/hecka.h, HECKA_GEMM_AUTO)."""
     L = _lib.lib()
     M, B, P = X.shape
     sbar = torch.empty((M, P), device=X.device, dtype=torch.float32)
+    xmax = torch.empty((M,), device=X.device, dtype=torch.float32)
     C = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
     cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
     st = _stream()
-    _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), st), 'colmean')
-    _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), M, B, P, _p(C), _p(cvec), st), 'gram_center')
-    return C, cvec
+    _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), _p(xmax), M, B, P, _p(C), _p(cvec), st), 'gram_center')
+    return (C, cvec, xmax) if return_xmax else (C, cvec)
 
 
 def pairwise_inner(Ca, Cb=None):
@@ -55,8 +58,9 @@ def pairwise_inner(Ca, Cb=None):
     return S
 
 
-def gram_backward(A, C, cvec, X, detach_diag):
-    """dX_i = (dC_i + dC_i^T, diag masked) X_i with dC_i = sum_j A[i,j] C[j]."""
+def gram_backward(A, C, cvec, X, detach_diag, xmax=None):
+    """dX_i = (dC_i + dC_i^T, diag masked) X_i with dC_i = sum_j A[i,j] C[j].
+    xmax: [Ma] max |X_i| from centered_gram(return_xmax=True), or None."""
     L = _lib.lib()
     Ma, Mb = A.shape
     B, P = X.shape[1], X.shape[2]
@@ -65,11 +69,14 @@ def gram_backward(A, C, cvec, X, detach_diag):
     W = torch.empty((Ma, B, B), device=X.device, dtype=torch.float32)
     dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), st), 'coef_gamma')
-    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W), st), 'combine')
+    wmax = torch.empty((Ma,), device=X.device, dtype=torch.float32) if xmax is not None else None
+    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W),
+                                   _p(wmax) if wmax is not None else None, st), 'combine')
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), Ma, B, P, _p(dX), st), 'gram_bwd')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), _p(wmax) if wmax is not None else None,
+                                    _p(xmax) if xmax is not None else None, Ma, B, P, _p(dX), st), 'gram_bwd')
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
@@ -89,10 +96,10 @@ class CenteredGramPairwise(torch.autograd.Function):
     def forward(ctx, X, detach_diag, left_only):
         _check_features(X)
         X = X.contiguous()
-        C, cvec = centered_gram(X)
+        C, cvec, xmax = centered_gram(X, True)
         S = pairwise_inner(C)
         nsq = torch.diagonal(S).clone()
-        ctx.save_for_backward(X, C, cvec)
+        ctx.save_for_backward(X, C, cvec, xmax)
         ctx.detach_diag, ctx.left_only = bool(detach_diag), bool(left_only)
         ctx.mark_non_differentiable(C)
         ctx.set_materialize_grads(False)
@@ -100,14 +107,14 @@ class CenteredGramPairwise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dS, dnsq, _dC):
-        X, C, cvec = ctx.saved_tensors
+        X, C, cvec, xmax = ctx.saved_tensors
         M = X.shape[0]
         A = torch.zeros((M, M), device=X.device, dtype=torch.float32)
         if dS is not None:
             A = A + (dS if ctx.left_only else dS + dS.t())
         if dnsq is not None:
             A = A + torch.diag_embed(2.0 * dnsq)
-        dX = gram_backward(A.contiguous(), C, cvec, X, ctx.detach_diag)
+        dX = gram_backward(A.contiguous(), C, cvec, X, ctx.detach_diag, xmax)
         return dX, None, None
 
 
@@ -161,7 +168,7 @@ class LinearGram(torch.autograd.Function):
         zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
         K = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
         cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
-        _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), M, B, P, _p(K), _p(cvec), _stream()), 'gram')
+        _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(K), _p(cvec), _stream()), 'gram')
         ctx.save_for_backward(X)
         ctx.detach_diag = bool(detach_diag)
         return K
@@ -176,7 +183,7 @@ class LinearGram(torch.autograd.Function):
         dX = torch.empty_like(X)
         st = _stream()
         _lib.check(L.hecka_symmetrize_f32(_p(dK), M, B, int(ctx.detach_diag), _p(W), st), 'symmetrize')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
         return dX, None
 
 
@@ -244,7 +251,7 @@ def raw_gram(X):
     zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
     G = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
     scratch = torch.empty((M, B), device=X.device, dtype=torch.float32)
-    _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), M, B, P, _p(G), _p(scratch), _stream()), 'gram')
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(G), _p(scratch), _stream()), 'gram')
     return G
 
 
@@ -277,10 +284,10 @@ def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec):
     W = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
     dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(rmean), M, M, B, _p(rho), st), 'coef_gamma')
-    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), st), 'combine')
+    _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), None, st), 'combine')
     _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(C), _p(rmean), _p(gdiag), _p(hband), M, B, gspec.kind, st),
                'gram_transform_bwd')
-    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
     return dX
 
 
@@ -299,8 +306,8 @@ class DiversityLayer(torch.autograd.Function):
         L = _lib.lib()
         M = X.shape[0]
         if gspec is None or gspec.kind == GRAM_LINEAR:
-            C, cvec = centered_gram(X)
-            aux = (cvec,)
+            C, cvec, xmax = centered_gram(X, True)
+            aux = (cvec, xmax)
         else:
             C, rmean, gdiag, hband = transformed_gram(X, gspec, True)
             aux = (rmean, gdiag, hband)
@@ -335,8 +342,8 @@ class DiversityLayer(torch.autograd.Function):
         up_mat, up_scalar = (None, _p(dout)) if ctx.reduced else (_p(dout), None)
         _lib.check(L.hecka_head_bwd_f32(_p(S), _p(nsq), M, M, 0, *ctx.spec.args(), up_mat, up_scalar, ctx.scale, _p(A),
                                         _stream()), 'head_bwd')
-        if len(aux) == 1:
-            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag)
+        if len(aux) == 2:
+            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag, aux[1])
         else:
             dX = transformed_gram_backward(A, C, aux[0], aux[1], aux[2], X, ctx.gspec)
         return dX, None, None, None, None
@@ -404,7 +411,7 @@ class TransformedGram(torch.autograd.Function):
         _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
         _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(K), None, _p(gdiag), _p(hband), M, B, ctx.gspec.kind, st),
                    'gram_transform_bwd')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
         return dX, None
 
 

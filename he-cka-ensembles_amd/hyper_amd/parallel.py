@@ -33,15 +33,15 @@ class _ShardedLayers(torch.autograd.Function):
         grams, works = [], []
         for X in feats:                                   # local Grams; exchanges run behind them
             X = X.contiguous()
-            C, cvec = backend.centered_gram(X)
+            C, cvec, xmax = backend.centered_gram(X, True)   # xmax: local members' max |X| (dX GEMM scaling)
             C_all = torch.empty((M,) + tuple(C.shape[1:]), device=C.device, dtype=C.dtype)
             cv_all = torch.empty((M, cvec.shape[1]), device=C.device, dtype=C.dtype)
             works.append((dist.all_gather_into_tensor(C_all, C, group=group, async_op=True),
                           dist.all_gather_into_tensor(cv_all, cvec, group=group, async_op=True)))
-            grams.append((X, C, C_all, cv_all))
+            grams.append((X, C, C_all, cv_all, xmax))
         total = None
         saved = []
-        for (X, C, C_all, cv_all), (w1, w2), spec, wl in zip(grams, works, specs, weights):
+        for (X, C, C_all, cv_all, xmax), (w1, w2), spec, wl in zip(grams, works, specs, weights):
             w1.wait()
             w2.wait()
             S = backend.pairwise_inner(C, C_all)                        # [Ml, M]
@@ -52,7 +52,7 @@ class _ShardedLayers(torch.autograd.Function):
             scale = float(wl) / count
             _, part = backend.head_forward(S, nsq, r0, spec, scale)
             total = part if total is None else total + part
-            saved.append((X, C_all, cv_all, S, nsq, spec, scale))
+            saved.append((X, C_all, cv_all, S, nsq, spec, scale, xmax))
         total = total.clone()
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
         ctx.saved, ctx.backend, ctx.r0, ctx.detach = saved, backend, r0, detach
@@ -62,9 +62,9 @@ class _ShardedLayers(torch.autograd.Function):
     def backward(ctx, dloss):
         dloss = dloss.contiguous().float()
         grads = []
-        for X, C_all, cv_all, S, nsq, spec, scale in ctx.saved:
+        for X, C_all, cv_all, S, nsq, spec, scale, xmax in ctx.saved:
             A = ctx.backend.head_backward(S, nsq, ctx.r0, spec, dloss, scale)
-            grads.append(ctx.backend.gram_backward(A, C_all, cv_all, X, ctx.detach))
+            grads.append(ctx.backend.gram_backward(A, C_all, cv_all, X, ctx.detach, xmax))
         return (None,) + tuple(grads)
 
 

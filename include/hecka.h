@@ -31,29 +31,35 @@ int hecka_version(void);
 const char* hecka_last_error(void);
 
 /* Arithmetic of the two large GEMMs (hecka_gram_center_f32, hecka_gram_bwd_f32).  No counterpart in the reference
- * (torch.bmm picks its own algorithm); a process-wide tuning knob.
- *   HECKA_GEMM_AUTO (default): interior shapes (B % 128 == 0, P % 16 == 0 resp. P % 128 == 0) run on the bf16
- *     matrix cores with every fp32 operand split exactly into three bf16 terms and six products per a*b, partial
- *     sums folded with round-to-nearest fp32 adds - measured error <= 7e-7 of sum|a.b| at K = 8192, smaller than
- *     the fp32-MFMA path's 2.5e-6; other shapes use fp32 MFMA.
- *   HECKA_GEMM_FP32: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
+ * (torch.bmm picks its own algorithm); a process-wide tuning knob.  Interior shapes (B % 128 == 0 and P % 16 == 0
+ * resp. P % 128 == 0) run on the 16-bit matrix cores with fp32 operands split EXACTLY into 16-bit terms, partial
+ * sums over 64 k folded into the running sum with round-to-nearest fp32 adds; other shapes use fp32 MFMA.
+ *   HECKA_GEMM_AUTO (default): "f16x3" when the caller supplies the operands' absolute maxima (xmax / wmax below):
+ *     x * 2^e = h + l, two fp16 terms (22 significand bits), three products hh + hl + lh per a*b; the power-of-two
+ *     scale 2^e comes from the maximum, so an element below 2^-17 of its member's maximum loses relative (not
+ *     absolute) precision.  Measured error <= 6e-7 of sum|a.b| at K = 8192 (fp32 MFMA: 2.5e-6).  Without maxima:
+ *     "bf16x6" - three bf16 terms (24 bits), six products, no scaling, no range assumption; error <= 4e-7.
+ *   HECKA_GEMM_BF16X6: never f16x3.     HECKA_GEMM_FP32: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
 #define HECKA_GEMM_AUTO 0
 #define HECKA_GEMM_FP32 1
+#define HECKA_GEMM_BF16X6 2
 int hecka_set_gemm_mode(int mode);
 int hecka_get_gemm_mode(void);
 
 /* Column mean of each member's features: sbar[m,p] = (1/B) sum_b X[m,b,p].
  * First half of the fused replacement of center_gram (hyper/diversity/kernels.py:335-345):
- * C = K - rowmean(K) == X (X - 1 sbar^T)^T, so the centring is applied to the features. */
-int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, void* stream);
+ * C = K - rowmean(K) == X (X - 1 sbar^T)^T, so the centring is applied to the features.
+ * xmax (may be NULL): [M] side output max |X[m]| for the f16x3 GEMMs (zeroed and filled by this call). */
+int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* xmax, void* stream);
 
 /* Centred linear Gram of every member, written once:
  *   C[m] = X_m X_m^T - rowmean(X_m X_m^T)   ([M,B,B]),   cvec[m,b] = sbar_m . (x_b - sbar_m)  ([M,B])
  * computed as Kt = (X-1 sbar^T)(X-1 sbar^T)^T on fp32 MFMA (upper-triangular tiles, mirrored) and
  * C = Kt + 1 cvec^T.  Replaces linear_gram + detach_diagonal(forward value) + center_gram
  * (hyper/diversity/kernels.py:107-127, 76-104, 335-345) as called from FeatureKernel.batched_kernel
- * (hyper/diversity/model_kernels.py:84-123) and HEModelKernel.forward (:369-377). */
-int hecka_gram_center_f32(const float* X, const float* sbar, int M, int B, int P,
+ * (hyper/diversity/model_kernels.py:84-123) and HEModelKernel.forward (:369-377).
+ * xmax (may be NULL): [M] max |X[m]| from hecka_colmean_f32; enables f16x3 (see HECKA_GEMM_AUTO). */
+int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P,
                           float* C, float* cvec, void* stream);
 
 /* Pairwise inner products of vectorised Grams: S[i,j] = <Ca[i,:], Cb[j,:]>, Ca [Ma,K], Cb [Mb,K],
@@ -97,9 +103,10 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
  *   diag(W_i) = 0 when detach_diag.
  * A [Ma,Mb] is dLoss/dS symmetrised by the caller, C [Mb,B,B], gamma [Ma,B], W [Ma,B,B].
  * Replaces autograd's backward of matmul/normalise/center_gram/detach_diagonal
- * (ParticleMethods.backward, hyper/diversity/methods.py:139-152). */
+ * (ParticleMethods.backward, hyper/diversity/methods.py:139-152).
+ * wmax (may be NULL): [Ma] side output max |W_i| for the f16x3 dX GEMM (zeroed and filled by this call). */
 int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B,
-                      int detach_diag, float* W, void* stream);
+                      int detach_diag, float* W, float* wmax, void* stream);
 
 /* out = A V   (A [Ma,Mb], V [Mb,K], out [Ma,K]) — backward of the generic pairwise inner product
  * (autograd of the matmul in hyper/diversity/__init__.py:47,108 for Grams that did not come from
@@ -142,8 +149,10 @@ int hecka_bgemm_f32(const float* A, const float* B, float* C, int batch, int row
                     void* stream);
 
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
- * (hyper/diversity/kernels.py:122) on fp32 MFMA. */
-int hecka_gram_bwd_f32(const float* W, const float* X, int M, int B, int P, float* dX, void* stream);
+ * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
+ * hecka_colmean_f32; both given enables f16x3 (see HECKA_GEMM_AUTO). */
+int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,
+                       float* dX, void* stream);
 
 #ifdef __cplusplus
 }

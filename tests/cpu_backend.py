@@ -10,9 +10,9 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def centered_gram(X):
+def centered_gram(X, return_xmax=False):
     C, c, _ = CF.forward_stats(X.double().numpy())
-    return _t(C), _t(c)
+    return (_t(C), _t(c), X.abs().amax(dim=(1, 2))) if return_xmax else (_t(C), _t(c))
 
 
 def pairwise_inner(Ca, Cb=None):
@@ -58,7 +58,7 @@ def head_backward(S, nsq, r0, spec, up_scalar, scale, up_mat=None):
     return _t(A)
 
 
-def gram_backward(A, C_all, cv_all, X, detach_diag):
+def gram_backward(A, C_all, cv_all, X, detach_diag, xmax=None):
     A, C, c, Xn = A.numpy(), C_all.numpy(), cv_all.numpy(), X.double().numpy()
     B = Xn.shape[1]
     dC = np.einsum('mj,jab->mab', A, C)

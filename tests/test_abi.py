@@ -20,10 +20,11 @@ def test_library_exports_every_declared_symbol():
 def test_bad_arguments_return_error_codes_without_a_gpu():
     from hyper_amd import _lib
     lib = _lib.lib()
-    assert lib.hecka_colmean_f32(None, 1, 1, 1, None, None) == -1
+    assert lib.hecka_colmean_f32(None, 1, 1, 1, None, None, None) == -1
     assert lib.hecka_pairwise_workspace_bytes(0, 1, 1) == 0
     assert lib.hecka_pairwise_workspace_bytes(64, 64, 512 * 512) > 0
     assert lib.hecka_set_gemm_mode(7) == -1 and lib.hecka_get_gemm_mode() == 0
+    assert lib.hecka_set_gemm_mode(2) == 0 and lib.hecka_get_gemm_mode() == 2
     assert lib.hecka_set_gemm_mode(1) == 0 and lib.hecka_get_gemm_mode() == 1
     assert lib.hecka_set_gemm_mode(0) == 0
 

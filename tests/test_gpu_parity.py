@@ -133,9 +133,10 @@ def test_bench_shape_properties():
 
 @pytest.mark.parametrize('M,B,P', [(8, 256, 80), (16, 128, 48), (3, 128, 144), (5, 384, 1024), (64, 512, 512)])
 def test_gemm_modes_against_fp64(M, B, P):
-    """Interior shapes run the two large GEMMs on the bf16 matrix cores with exactly split fp32 operands
-    (HECKA_GEMM_AUTO); HECKA_GEMM_FP32 forces fp32 MFMA.  Both against fp64 torch on the GPU, the bf16x6
-    path to the SAME tolerance as the fp32 one (2e-6 of the largest entry for the Gram, 1e-5 for dX)."""
+    """Interior shapes run the two large GEMMs on the 16-bit matrix cores with exactly split fp32 operands
+    (HECKA_GEMM_AUTO: f16x3, HECKA_GEMM_BF16X6); HECKA_GEMM_FP32 forces fp32 MFMA.  All against fp64 torch on
+    the GPU, the split paths to the SAME tolerance as the fp32 one (2e-6 of the largest entry for the Gram,
+    1e-5 for dX)."""
     from hyper_amd import ops, _lib
     dev = _dev()
     g = torch.Generator().manual_seed(M + B + P)
@@ -149,16 +150,44 @@ def test_gemm_modes_against_fp64(M, B, P):
     dref = Wd @ Xd
     L = _lib.lib()
     try:
-        for mode in (0, 1):
+        for mode in (0, 2, 1):   # f16x3 (two fp16 terms, scaled by xmax / wmax), bf16x6, fp32 MFMA
             assert L.hecka_set_gemm_mode(mode) == 0
-            C, cvec = ops.centered_gram(X)
+            C, cvec, xmax = ops.centered_gram(X, True)
+            assert torch.equal(xmax, X.abs().amax(dim=(1, 2)))
             assert float((C.double() - Cref).abs().max() / Cref.abs().max()) <= 2e-6, mode
             cref = ((Xd - Xd.mean(1, keepdim=True)) * Xd.mean(1, keepdim=True)).sum(2)
             assert float((cvec.double() - cref).abs().max() / cref.abs().max()) <= 1e-5, mode
-            dX = ops.gram_backward(A, C, cvec, X, True)
+            dX = ops.gram_backward(A, C, cvec, X, True, xmax)
             assert float((dX.double() - dref).abs().max() / dref.abs().max()) <= 1e-5, mode
     finally:
         L.hecka_set_gemm_mode(0)
+
+
+def test_f16x3_scaling_over_dynamic_range():
+    """The fp16-split path scales every member by a power of two from its max |x|: members of very different
+    magnitude (1e-12 .. 1e+7; dX ~ |x|^3 stays inside fp32) and features spanning four decades inside a member keep the fp32-level
+    accuracy, per member (relative to that member's own largest Gram entry)."""
+    from hyper_amd import ops, _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(99)
+    M, B, P = 8, 128, 256
+    X = torch.randn(M, B, P, generator=g) + 0.3
+    X = X * (10.0 ** torch.linspace(-2, 2, P))[None, None, :]                      # four decades across features
+    X = (X * torch.tensor([1e-12, 1e-6, 1e-3, 1.0, 7.0, 1e3, 1e5, 1e7])[:, None, None]).to(dev)
+    Xd = X.double()
+    K = Xd @ Xd.transpose(1, 2)
+    Cref = K - K.mean(2, keepdim=True)
+    assert _lib.lib().hecka_get_gemm_mode() == 0
+    C, cvec, xmax = ops.centered_gram(X, True)
+    err = (C.double() - Cref).abs().amax(dim=(1, 2)) / Cref.abs().amax(dim=(1, 2))
+    assert float(err.max()) <= 2e-6, err
+    A = torch.eye(M, device=dev)                                                    # dC_i = C_i: every member on its own scale
+    dX = ops.gram_backward(A, C, cvec, X, True, xmax)
+    gam = cvec.double()
+    Wd = (2 * Cref + gam[:, :, None] - gam[:, None, :]) * (1 - torch.eye(B, dtype=torch.float64, device=dev))
+    dref = Wd @ Xd
+    errd = (dX.double() - dref).abs().amax(dim=(1, 2)) / dref.abs().amax(dim=(1, 2))
+    assert float(errd.max()) <= 1e-5, errd
 
 
 @pytest.mark.parametrize('P,style', [(512, 'randn'), (2048, 'correlated')])
@@ -217,7 +246,7 @@ def test_errors_are_loud():
     """Bad arguments come back as error codes / exceptions, never as silent fallbacks."""
     from hyper_amd import _lib, ops
     L = _lib.lib()
-    assert L.hecka_colmean_f32(None, 1, 1, 1, None, None) == -1
+    assert L.hecka_colmean_f32(None, 1, 1, 1, None, None, None) == -1
     assert b'null' in L.hecka_last_error()
     with pytest.raises(RuntimeError):
         ops.centered_gram_pairwise(torch.randn(2, 4, 3))          # CPU tensor: no CPU path

@@ -27,18 +27,21 @@ W = torch.randn(M, B, B, device=dev)
 dX = torch.empty_like(X)
 A = torch.randn(M, M, device=dev)
 gamma = torch.randn(M, B, device=dev)
-L.hecka_colmean_f32(p(X), M, B, P, p(sbar), st)
-L.hecka_gram_center_f32(p(X), p(sbar), M, B, P, p(C), p(cvec), st)
+xmax = torch.empty(M, device=dev)
+wmax = torch.empty(M, device=dev)
+L.hecka_colmean_f32(p(X), M, B, P, p(sbar), p(xmax), st)
+L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), st)
 nb = L.hecka_pairwise_workspace_bytes(M, M, B * B)
 ws = torch.empty(max(nb, 4) // 4, device=dev)
 S = torch.empty(M, M, device=dev)
 fns = {
-    'colmean': (lambda: L.hecka_colmean_f32(p(X), M, B, P, p(sbar), st), 0, 4.0 * M * B * P),
-    'gram_center': (lambda: L.hecka_gram_center_f32(p(X), p(sbar), M, B, P, p(C), p(cvec), st), 2.0 * M * B * B * P, 0),
+    'colmean': (lambda: L.hecka_colmean_f32(p(X), M, B, P, p(sbar), p(xmax), st), 0, 4.0 * M * B * P),
+    'gram_center': (lambda: L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), st), 2.0 * M * B * B * P, 0),
     'pairwise': (lambda: L.hecka_pairwise_f32(p(C), M, p(C), M, B * B, p(S), p(ws), nb, st), 2.0 * M * M * B * B, 4.0 * M * B * B),
-    'combine': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), st), 2.0 * M * M * B * B, 8.0 * M * B * B),
-    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), M, B, P, p(dX), st), 2.0 * M * B * B * P, 0),
+    'combine': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st), 2.0 * M * M * B * B, 8.0 * M * B * B),
+    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), p(wmax), p(xmax), M, B, P, p(dX), st), 2.0 * M * B * B * P, 0),
 }
+L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st)   # W and wmax consistent for gram_bwd
 fn, flops, nbytes = fns[name]
 for _ in range(3):
     assert fn() == 0
