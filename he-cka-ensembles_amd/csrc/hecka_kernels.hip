@@ -762,6 +762,64 @@ __global__ __launch_bounds__(kThreads, 2) void bgemm_kernel(GemmOperands g, floa
   });
 }
 
+// ------------------------------------------------------------------------------------------
+// (11) batched-weight Conv2d as grouped GEMMs: patch gather / scatter around hecka_bgemm_f32.
+//      cols[m] is [R, Q]: R = C*kh*kw (+1 row of ones that carries the bias through the GEMM), Q = N*Ho*Wo.
+//      HBM-bound gathers; zero padding only.
+// ------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, ConvGeom g, int ones_row,
+                                                     float* __restrict__ cols) {
+  const long long Q = (long long)g.N * g.Ho * g.Wo;
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= Q) return;
+  const int r = blockIdx.y, m = blockIdx.z;
+  const int K = g.C * g.kh * g.kw, R = K + (ones_row ? 1 : 0);
+  float v;
+  if (r == K) {
+    v = 1.0f;
+  } else {
+    const int j = r % g.kw, i = (r / g.kw) % g.kh, c = r / (g.kw * g.kh);
+    const int ow = (int)(q % g.Wo), oh = (int)((q / g.Wo) % g.Ho), n = (int)(q / ((long long)g.Wo * g.Ho));
+    const int h = oh * g.sh - g.ph + i * g.dh, w = ow * g.sw - g.pw + j * g.dw;
+    v = (h >= 0 && h < g.H && w >= 0 && w < g.W)
+            ? x[((((size_t)m * g.N + n) * g.C + c) * g.H + h) * g.W + w]
+            : 0.0f;
+  }
+  cols[((size_t)m * R + r) * Q + q] = v;
+}
+
+// dx[m,n,c,h,w] = sum over the patches that read this pixel (a gather: deterministic, no atomics)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, ConvGeom g, int R,
+                                                     float* __restrict__ dx) {
+  const long long total = (long long)g.N * g.C * g.H * g.W;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int m = blockIdx.y;
+  const int w = (int)(e % g.W), h = (int)((e / g.W) % g.H), c = (int)((e / ((long long)g.W * g.H)) % g.C);
+  const int n = (int)(e / ((long long)g.W * g.H * g.C));
+  const long long Q = (long long)g.N * g.Ho * g.Wo;
+  float acc = 0.f;
+  for (int i = 0; i < g.kh; ++i) {
+    const int hn = h + g.ph - i * g.dh;
+    if (hn < 0 || hn % g.sh) continue;
+    const int oh = hn / g.sh;
+    if (oh >= g.Ho) continue;
+    for (int j = 0; j < g.kw; ++j) {
+      const int wn = w + g.pw - j * g.dw;
+      if (wn < 0 || wn % g.sw) continue;
+      const int ow = wn / g.sw;
+      if (ow >= g.Wo) continue;
+      const int r = (c * g.kh + i) * g.kw + j;
+      acc += dcols[((size_t)m * R + r) * Q + ((long long)n * g.Ho + oh) * g.Wo + ow];
+    }
+  }
+  dx[(size_t)m * total + e] = acc;
+}
+
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -1057,6 +1115,45 @@ int hecka_bgemm_f32(const float* A, const float* Bm, float* C, int batch, int ro
   }
 #undef HECKA_BGEMM
   return check_launch("bgemm");
+}
+
+static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                     int dw, const char* who) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0 || dh <= 0 ||
+      dw <= 0)
+    return fail(HECKA_EINVAL, "%s: bad convolution geometry", who);
+  const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+  if (H + 2 * ph < dh * (kh - 1) + 1 || W + 2 * pw < dw * (kw - 1) + 1 || Ho <= 0 || Wo <= 0)
+    return fail(HECKA_EINVAL, "%s: kernel larger than the padded input", who);
+  g = ConvGeom{N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo};
+  return HECKA_OK;
+}
+
+int hecka_im2col_f32(const float* x, int Mx, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                     int dh, int dw, int ones_row, float* cols, void* stream) {
+  clear_error();
+  if (!x || !cols) return fail(HECKA_EINVAL, "im2col: null pointer%s");
+  ConvGeom g;
+  if (int rc = conv_geom(g, N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, "im2col")) return rc;
+  const long long Q = (long long)N * g.Ho * g.Wo;
+  const int R = C * kh * kw + (ones_row ? 1 : 0);
+  if (Mx <= 0 || Mx > 65535 || R > 65535 || Q > (1ll << 38)) return fail(HECKA_EINVAL, "im2col: size out of range%s");
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Q + 255) / 256), R, Mx), dim3(256), 0, (hipStream_t)stream, x, g,
+                     ones_row, cols);
+  return check_launch("im2col");
+}
+
+int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                     int pw, int dh, int dw, int rows, float* dx, void* stream) {
+  clear_error();
+  if (!dcols || !dx) return fail(HECKA_EINVAL, "col2im: null pointer%s");
+  ConvGeom g;
+  if (int rc = conv_geom(g, N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, "col2im")) return rc;
+  if (M <= 0 || M > 65535 || rows < C * kh * kw) return fail(HECKA_EINVAL, "col2im: size out of range%s");
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream, dcols, g,
+                     rows, dx);
+  return check_launch("col2im");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,

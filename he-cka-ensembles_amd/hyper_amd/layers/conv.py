@@ -1,0 +1,228 @@
+"""Batched-weight Conv2d (hyper/layers/conv.py:16-208 `_ConvNd`, :215-346 `Conv2d`, :434-502 `_conv_forward`).
+The reference loops F.conv2d over the ensemble members and stacks the results; here all members go through ONE
+grouped GEMM on fp32 MFMA: patches are gathered once (libhecka hecka_im2col_f32, shared across members when the
+input is a plain image batch), forward / wgrad / dgrad are hecka_bgemm_f32 calls with the parameter scaling in the
+epilogue and the bias carried as an extra weight column against a row of ones, and hecka_col2im_f32 gathers the
+input gradient.  Patches are re-gathered in backward instead of being kept (R*Q floats per member)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.nn.init as init
+from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
+
+from .. import _lib
+from ..net import activation
+from .linear import _bgemm
+from .module import ParametersGroup, register_gen_module
+
+
+def _out_size(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def _im2col(x5, geom, ones_row):
+    """x5 [Mx,N,C,H,W] -> cols [Mx,R,Q]"""
+    Mx, N, C, H, W = x5.shape
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    Q = N * _out_size(H, kh, sh, ph, dh) * _out_size(W, kw, sw, pw, dw)
+    R = C * kh * kw + (1 if ones_row else 0)
+    cols = torch.empty((Mx, R, Q), device=x5.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_im2col_f32(x5.data_ptr(), Mx, N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw,
+                                           int(ones_row), cols.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               'im2col')
+    return cols
+
+
+def _col2im(dcols, M, N, C, H, W, geom):
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    dx = torch.empty((M, N, C, H, W), device=dcols.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_col2im_f32(dcols.data_ptr(), M, N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw,
+                                           dcols.shape[1], dx.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               'col2im')
+    return dx
+
+
+class BatchedConv2d(torch.autograd.Function):
+    """y[m] = conv2d(x[m] | x, scale * W[m], bias_scale * b[m]);  x [M,N,C,H,W] or [N,C,H,W] (shared),
+    W [M,O,C,kh,kw], b [M,O] | None  ->  y [M,N,O,Ho,Wo].  groups = 1, zero padding."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, scale, bias_scale, geom):
+        if not (x.is_cuda and W.is_cuda) or x.dtype != torch.float32 or W.dtype != torch.float32:
+            raise RuntimeError('hyper_amd Conv2d needs fp32 GPU tensors; there is no CPU path')
+        M, O, C, kh, kw = W.shape
+        shared = x.ndim == 4
+        x5 = (x.unsqueeze(0) if shared else x).contiguous()
+        Mx, N, _, H, Wd = x5.shape
+        Ho, Wo = _out_size(H, kh, geom[2], geom[4], geom[6]), _out_size(Wd, kw, geom[3], geom[5], geom[7])
+        if Ho <= 0 or Wo <= 0:
+            raise RuntimeError('Conv2d kernel %s is larger than the padded input %s' % ((kh, kw), (H, Wd)))
+        K, Q = C * kh * kw, N * Ho * Wo
+        has_bias = b is not None
+        cols = _im2col(x5, geom, has_bias)
+        Wf = W.reshape(M, O, K)
+        if has_bias:      # bias rides as weight column K against the row of ones; alpha = scale rescales it
+            Wf = torch.cat([Wf, (bias_scale / scale) * b.reshape(M, O, 1)], dim=2)
+        Wf = Wf.contiguous()
+        R = Wf.shape[2]
+        y = _bgemm(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale)      # [M,O,Q]
+        ctx.save_for_backward(x5, W)
+        ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
+        return y.view(M, O, N, Ho, Wo).transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x5, W = ctx.saved_tensors
+        scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo) = ctx.cfg
+        M, O, C, kh, kw = W.shape
+        K, Q = C * kh * kw, N * Ho * Wo
+        dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            cols = _im2col(x5, geom, has_bias)
+            R = cols.shape[1]
+            dWf = _bgemm(dyq, cols, M, O, R, Q, O * Q, 0 if shared else R * Q, False, scale)   # dy cols^T  [M,O,R]
+            dW = dWf[:, :, :K].reshape(W.shape)
+            if has_bias:
+                db = dWf[:, :, K] * (bias_scale / scale)
+            del cols
+        if ctx.needs_input_grad[0]:
+            Wt = W.reshape(M, O, K).transpose(1, 2).contiguous()                              # [M,K,O]
+            dcols = _bgemm(Wt, dyq, M, K, Q, O, K * O, O * Q, True, scale)                     # W^T dy  [M,K,Q]
+            dx = _col2im(dcols, M, N, C, x5.shape[3], x5.shape[4], geom)
+            dx = dx.sum(0) if shared else dx
+        return dx, dW, db, None, None, None
+
+
+CONV2D_DEFAULT_POOLING_ARGS = {'kernel_size': 2}
+_POOLING = {'max': F.max_pool2d, 'avg': F.avg_pool2d,
+            'adaptive_max': F.adaptive_avg_pool2d,       # sic: the reference maps both names to the avg pool
+            'adaptive_avg': F.adaptive_avg_pool2d}
+
+
+class _ConvNd(ParametersGroup):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, transposed, output_padding,
+                 groups, bias, padding_mode, act=None, gamma=1.0, param_scale='torch', track=True):
+        if groups <= 0:
+            raise ValueError('groups must be a positive integer')
+        if in_channels % groups != 0:
+            raise ValueError('in_channels must be divisible by groups')
+        if out_channels % groups != 0:
+            raise ValueError('out_channels must be divisible by groups')
+        if isinstance(padding, str):
+            if padding not in ('same', 'valid'):
+                raise ValueError("Invalid padding string %r, should be one of {'same', 'valid'}" % padding)
+            if padding == 'same' and any(s != 1 for s in stride):
+                raise ValueError("padding='same' is not supported for strided convolutions")
+        if padding_mode not in ('zeros', 'reflect', 'replicate', 'circular'):
+            raise ValueError("padding_mode must be one of zeros/reflect/replicate/circular, but got padding_mode='%s'"
+                             % padding_mode)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.transposed, self.output_padding, self.groups = transposed, output_padding, groups
+        self.padding_mode, self.param_scale, self.bias = padding_mode, param_scale, bias
+        if isinstance(padding, str):
+            self._reversed_padding_repeated_twice = [0, 0] * len(kernel_size)
+            if padding == 'same':
+                for d, k, i in zip(dilation, kernel_size, range(len(kernel_size) - 1, -1, -1)):
+                    total = d * (k - 1)
+                    self._reversed_padding_repeated_twice[2 * i] = total // 2
+                    self._reversed_padding_repeated_twice[2 * i + 1] = total - total // 2
+        else:
+            self._reversed_padding_repeated_twice = _reverse_repeat_tuple(padding, 2)
+        self.weight_shape = ((in_channels, out_channels // groups) if transposed
+                             else (out_channels, in_channels // groups)) + tuple(kernel_size)
+        self.bias_shape = (out_channels,)
+        self.fan_in = (in_channels // groups) * int(np.prod(kernel_size))
+        if param_scale == 'gamma':
+            self.invsq = math.sqrt(1 / self.fan_in)
+            self.gamma = activation.activation_gamma(gamma)
+            self.scale = self.gamma * self.invsq
+            self.bias_scale = self.invsq
+        elif param_scale == 'torch':
+            gain = init.calculate_gain('leaky_relu', math.sqrt(5.0))
+            self.scale = math.sqrt(gain / math.sqrt(self.fan_in))
+            self.bias_scale = math.sqrt(1.0 / math.sqrt(self.fan_in))
+        else:
+            raise ValueError('Invalid paramater scaling method %s' % param_scale)
+        if isinstance(act, str):
+            if hasattr(F, act):
+                act = getattr(F, act)
+            elif hasattr(activation, act):
+                act = getattr(activation, act)
+            else:
+                raise ValueError('Could not find activation %s in either torch.nn.functional or net.activation' % act)
+        self.act = act
+        shapes = [('weight', self.weight_shape)] + ([('bias', self.bias_shape)] if bias else [])
+        super().__init__(shapes=shapes, track=track)
+
+    def gen_initialized_params(self, dtype=None, device=None, gain=1.0):
+        if gain is None or not isinstance(gain, float):
+            raise ValueError('Gain must be a float')
+        params = self.gen_empty_params(dtype=dtype, device=device)
+        with torch.no_grad():
+            for p in params.values():
+                if self.param_scale == 'gamma':
+                    init.normal_(p, 0.0, 1.0)
+                else:
+                    init.uniform_(p, -math.sqrt(3.0), math.sqrt(3.0))
+        return params
+
+
+@register_gen_module('conv2d')
+class Conv2d(_ConvNd):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode='zeros', act=None, pooling=None, pooling_kwargs=CONV2D_DEFAULT_POOLING_ARGS, gamma=1.0,
+                 param_scale='torch', track=True):
+        if isinstance(pooling, str):
+            if pooling not in _POOLING:
+                raise KeyError('Provided pooling "%s" was not found. Available keys: %s' % (pooling, ', '.join(_POOLING)))
+            pooling = _POOLING[pooling]
+        self.pooling, self.pooling_kwargs = pooling, pooling_kwargs
+        super().__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
+                         padding if isinstance(padding, str) else _pair(padding), _pair(dilation), False, _pair(0),
+                         groups, bias, padding_mode, act, gamma, param_scale, track)
+        if groups != 1:
+            raise NotImplementedError('hyper_amd Conv2d: groups > 1 is not built (no shipped config uses it)')
+
+    def _geometry(self):
+        if self.padding_mode != 'zeros' or isinstance(self.padding, str):
+            # the input is padded explicitly first (conv.py:306-316); 'same' pads asymmetrically for even kernels
+            return self.kernel_size + self.stride + (0, 0) + self.dilation
+        return self.kernel_size + self.stride + tuple(self.padding) + self.dilation
+
+    def _forward(self, viewed, x):
+        W = viewed['weight']
+        M = W.shape[0]
+        if x.ndim == 4:
+            assert x.shape[1] == self.in_channels, 'Input channel mismatch!'
+        elif x.ndim == 5:
+            assert x.shape[0] == M, 'Conv2d input x has wrong shape %s' % (tuple(x.shape),)
+            assert x.shape[2] == self.in_channels, 'Input channel mismatch!'
+        else:
+            raise RuntimeError('Invalid input shape to batched Conv2d %s expecting ndim to be 4 or 5' % (tuple(x.shape),))
+        if self.padding_mode != 'zeros' or (isinstance(self.padding, str) and self.padding == 'same'):
+            mode = 'constant' if self.padding_mode == 'zeros' else self.padding_mode
+            lead = x.shape[:-3]
+            x = F.pad(x.reshape((-1,) + x.shape[-3:]), self._reversed_padding_repeated_twice, mode=mode)
+            x = x.reshape(lead + x.shape[-3:])
+        y = BatchedConv2d.apply(x, W, viewed['bias'] if self.bias else None, self.scale, self.bias_scale,
+                                self._geometry())
+        if self.act is not None:
+            y = self.act(y)
+        if self.pooling is not None:
+            N = y.shape[1]
+            y = self.pooling(y.reshape((M * N,) + y.shape[2:]), **self.pooling_kwargs)
+            y = y.view((M, N) + y.shape[1:])
+        return y.contiguous()
+
+    def extra_repr(self):
+        return 'in_channels=%d, out_channels=%d, kernel_size=%s, stride=%s, padding=%s, groups=%d' % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.groups)
+
+
+@register_gen_module('final_conv2d')
+class FinalConv2d(Conv2d):
+    """Marker subclass: lets a generator treat the output layer differently."""

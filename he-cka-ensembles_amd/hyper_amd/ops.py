@@ -20,6 +20,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _features_f32(X):
+    """bf16 / fp16 features (BASELINE config 3) enter the fp32 kernels through a differentiable up-cast: every
+    16-bit value is exact in fp32, the kernels compute exactly as for fp32 input, and autograd casts dX back to
+    the feature dtype.  (Native 16-bit loads in the staging path would save the cast pass: next round.)"""
+    if X.is_cuda and X.dtype in (torch.bfloat16, torch.float16):
+        return X.float()
+    return X
+
+
 def _check_features(X):
     if not X.is_cuda:
         raise RuntimeError('hyper_amd kernels need features on the GPU (got %s); there is no CPU path' % X.device)
@@ -119,7 +128,7 @@ class CenteredGramPairwise(torch.autograd.Function):
 
 
 def centered_gram_pairwise(X, detach_diag=True, left_only=False):
-    return CenteredGramPairwise.apply(X, detach_diag, left_only)
+    return CenteredGramPairwise.apply(_features_f32(X), detach_diag, left_only)
 
 
 class PairwiseInner(torch.autograd.Function):
@@ -188,7 +197,7 @@ class LinearGram(torch.autograd.Function):
 
 
 def linear_gram(X, detach_diag=True):
-    return LinearGram.apply(X, detach_diag)
+    return LinearGram.apply(_features_f32(X), detach_diag)
 
 
 class CenterRows(torch.autograd.Function):
@@ -350,7 +359,7 @@ class DiversityLayer(torch.autograd.Function):
 
 
 def diversity_layer(X, spec, detach_diag=True, reduce=None, gspec=None):
-    return DiversityLayer.apply(X, spec, detach_diag, reduce, gspec)
+    return DiversityLayer.apply(_features_f32(X), spec, detach_diag, reduce, gspec)
 
 
 _OFFDIAG_INDEX = {}
@@ -416,4 +425,4 @@ class TransformedGram(torch.autograd.Function):
 
 
 def transformed_gram_ad(X, gspec):
-    return TransformedGram.apply(X, gspec)
+    return TransformedGram.apply(_features_f32(X), gspec)

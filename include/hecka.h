@@ -148,6 +148,17 @@ int hecka_bgemm_f32(const float* A, const float* B, float* C, int batch, int row
                     long long strideA, long long strideB, int nn, float alpha, const float* bias, float beta,
                     void* stream);
 
+/* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
+ * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
+ * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an
+ * extra weight column), Q = N*Ho*Wo, row r = (c*kh+i)*kw+j; zero padding.  Forward y[m] [O,Q] = W'[m] [O,R] cols[m],
+ * wgrad dW'[m] = dy[m] cols[m]^T, dgrad dcols[m] = W[m]^T dy[m] are hecka_bgemm_f32 calls; hecka_col2im_f32 gathers
+ * dcols [M,rows,Q] (rows >= C*kh*kw; extra rows ignored) back into dx [M,N,C,H,W] (deterministic, no atomics). */
+int hecka_im2col_f32(const float* x, int Mx, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                     int dh, int dw, int ones_row, float* cols, void* stream);
+int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                     int pw, int dh, int dw, int rows, float* dx, void* stream);
+
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
  * hecka_colmean_f32; both given enables f16x3 (see HECKA_GEMM_AUTO). */

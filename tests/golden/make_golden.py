@@ -173,10 +173,81 @@ def run_train_step(dtype, tag):
     print('toy_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']))
 
 
+MNIST = {
+    'hyper': {'name': 'ensemble', 'ensemble_size': 5, 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
+    'method': {'name': 'repulsive_kernel', 'num': 5, 'gamma': 10.5, 'warmup': 600,
+               'model_kernel': layers(he(eps=0.0025, arc_eps=0.031), MNIST_W), 'ind_loss': {'name': 'cross_entropy'}},
+}
+
+
+def run_lenet_step(dtype, tag):
+    """One training step of BASELINE configs[0] (configs/mnist/base.yml + ens/he-lin.yml: LeNet-5 x5, HE on the
+    linear-kernel Grams of the five tracked layers) with the REAL reference, batch of 16 MNIST-shaped images."""
+    import hyper.target.lenet  # noqa: F401  (registers `lenet5`)
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    torch.manual_seed(31)
+    hyper = build_generator(MNIST['hyper']).to(dtype)
+    method = build_method(MNIST['method']).to(dtype)
+    gen = torch.Generator().manual_seed(6)
+    X = torch.randn(16, 1, 28, 28, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 10, (16,), generator=gen)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=700)
+    track['loss'].backward()
+    rec = {'config': json.dumps(MNIST), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 700,
+           'loss': track['loss'].detach().numpy(), 'ind_loss': track['ind_loss'].detach().numpy(),
+           'ind_rep_loss': track['ind_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy(),
+           'feat_keys': json.dumps(list(track['feats_ind'].keys())),
+           'feat_shapes': json.dumps([list(v.shape) for v in track['feats_ind'].values()])}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'lenet_train_step_%s.npz' % tag), **rec)
+    print('lenet_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']))
+
+
+# name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
+CONV_CASES = {
+    'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
+                               gamma=1.0, param_scale='gamma'), 4, (6, 3, 9, 8)),
+    'conv_member_torch_nobias': (dict(in_channels=4, out_channels=7, kernel_size=3, stride=2, padding=1, bias=False,
+                                      act='relu', param_scale='torch'), 3, (3, 5, 4, 11, 10)),
+    'conv_dilated_rect': (dict(in_channels=2, out_channels=3, kernel_size=(3, 2), stride=(1, 2), padding=(2, 0),
+                               dilation=(2, 1), pooling='avg', param_scale='torch'), 3, (3, 4, 2, 10, 9)),
+    'conv_same_even': (dict(in_channels=2, out_channels=4, kernel_size=4, padding='same', param_scale='gamma',
+                            gamma='crater'), 2, (5, 2, 7, 7)),
+    'conv_reflect_1x1': (dict(in_channels=3, out_channels=2, kernel_size=1, padding=1, padding_mode='reflect',
+                              param_scale='torch'), 2, (2, 3, 3, 6, 5)),
+}
+
+
+def run_conv_case(name, kwargs, M, xshape, dtype):
+    """Reference batched Conv2d (hyper/layers/conv.py) forward + autograd: y, dx, dflat for seeded inputs."""
+    from hyper.layers.conv import Conv2d
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    conv = Conv2d(**kwargs)
+    flat = torch.randn(M, conv.single_flat_size(), generator=gen, dtype=torch.float64).to(dtype).requires_grad_(True)
+    x = torch.randn(*xshape, generator=gen, dtype=torch.float64).to(dtype).requires_grad_(True)
+    tracked, y = conv({'self': flat}, x)
+    up = torch.randn(y.shape, generator=gen, dtype=torch.float64).to(dtype)
+    (y * up).sum().backward()
+    return {'kwargs': json.dumps(kwargs), 'M': M, 'flat': flat.detach().numpy(), 'x': x.detach().numpy(),
+            'y': y.detach().numpy(), 'up': up.numpy(), 'dflat': flat.grad.numpy(), 'dx': x.grad.numpy()}
+
+
 def main():
     mk = _import_reference()
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         run_train_step(dtype, tag)
+        run_lenet_step(dtype, tag)
+    for name, (kwargs, M, xshape) in CONV_CASES.items():
+        rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
+        np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)
+        print(name, 'y', rec['y'].shape, float(np.abs(rec['y']).mean()))
     for name, (cfg, M, B, shapes, style) in CASES.items():
         for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
             rec = run_case(mk, name, cfg, M, B, shapes, style, dtype)

@@ -217,6 +217,30 @@ def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
         assert err <= RTOL, err
 
 
+def test_bf16_features_match_oracle_on_rounded_values():
+    """BASELINE config 3 / SURVEY.md 8d: bf16 features; oracle = the restatement in fp64 on the bf16-rounded
+    values.  north_star tolerance for bf16 features: rel 1e-2 (loss is in fact at the fp32 level; the gradient
+    is rounded to bf16 once, 2^-9)."""
+    from oracle import hecka_ref as R
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from collections import OrderedDict
+    dev = _dev()
+    torch.manual_seed(4)
+    cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+           'layer_kernel': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True,
+                                feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
+    xs = [torch.relu(torch.randn(10, 128, p, device=dev) + 0.3).bfloat16().requires_grad_(True) for p in (256, 1024)]
+    out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+    out.backward()
+    xo = [x.detach().double().requires_grad_(True) for x in xs]
+    ref = R.run_config(cfg, xo)
+    ref.backward()
+    assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    for x, o in zip(xs, xo):
+        assert x.grad.dtype == torch.bfloat16
+        assert float((x.grad.double() - o.grad).abs().max() / o.grad.abs().max()) <= 1e-2
+
+
 def test_learnable_head_matches_autograd_oracle():
     """learnable=True keeps the [M,M] head in torch: loss, dX, d eps and d arc_eps vs the oracle's autograd."""
     from oracle import hecka_ref as R
@@ -309,6 +333,66 @@ def test_toy_train_step_matches_reference_golden():
     Y = torch.from_numpy(z['Y']).to(dev)
     track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
     assert list(track['feats_ind'].keys()) == json.loads(str(z['feat_keys']))
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
+    track['loss'].backward()
+    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 1e-5
+    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
+    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 5e-5, k
+
+
+CONV_CASES = ['conv_shared_gamma', 'conv_member_torch_nobias', 'conv_dilated_rect', 'conv_same_even', 'conv_reflect_1x1']
+
+
+@pytest.mark.parametrize('name', CONV_CASES)
+def test_batched_conv2d_matches_reference_golden(name):
+    """hyper_amd Conv2d (im2col gather -> grouped MFMA GEMM -> col2im) vs the reference's per-member F.conv2d loop
+    (tests/golden/conv_*_f64.npz from the REAL reference): output, input gradient, flat parameter gradient."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from hyper_amd.layers.conv import Conv2d
+    z = np.load(os.path.join(GOLDEN, name + '_f64.npz'), allow_pickle=False)
+    kwargs = json.loads(str(z['kwargs']))
+    if isinstance(kwargs.get('kernel_size'), list):
+        kwargs = {k: tuple(v) if isinstance(v, list) else v for k, v in kwargs.items()}
+    dev = _dev()
+    conv = Conv2d(**kwargs)
+    flat = torch.from_numpy(z['flat']).float().to(dev).requires_grad_(True)
+    x = torch.from_numpy(z['x']).float().to(dev).requires_grad_(True)
+    tracked, y = conv({'self': flat}, x)
+    assert tracked is y and y.is_contiguous()
+    assert tuple(y.shape) == z['y'].shape
+    (y * torch.from_numpy(z['up']).float().to(dev)).sum().backward()
+    assert _relerr(y.detach().cpu().numpy(), z['y']) <= RTOL
+    assert _relerr(x.grad.cpu().numpy(), z['dx']) <= RTOL
+    assert _relerr(flat.grad.cpu().numpy(), z['dflat']) <= RTOL
+
+
+def test_lenet_train_step_matches_reference_golden():
+    """BASELINE configs[0] (MNIST LeNet-5 x5 with HE-CKA, configs/mnist/ens/he-lin.yml): one training step through
+    hyper_amd's FixedEnsembleModel -> batched Conv2d / Linear -> RepulsiveKernel -> backward against the step the
+    REAL reference produced on its CPU path (tests/golden/lenet_train_step_f64.npz, same weights and batch)."""
+    import json
+    import os
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'lenet_train_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    assert list(track['feats_ind'].keys()) == json.loads(str(z['feat_keys']))
+    assert [list(v.shape) for v in track['feats_ind'].values()] == json.loads(str(z['feat_shapes']))
     track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
     track['loss'].backward()
     assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 1e-5
