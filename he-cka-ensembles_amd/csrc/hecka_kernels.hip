@@ -820,6 +820,95 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
   dx[(size_t)m * total + e] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// (12) batched BatchNorm: x [G, N, C, S] (G = members, S = H*W), statistics per (member,
+//      channel) over N*S elements.  One workgroup per (channel, member): statistics and normalisation in one launch
+//      (two-pass variance in fp64 partial sums; the re-reads of the channel's N*S elements hit L2).  HBM-bound.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float* __restrict__ x, int N, int C, long long S,
+                                                            const float* __restrict__ weight, const float* __restrict__ bias,
+                                                            const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                            int training, float eps, float* __restrict__ y,
+                                                            float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                            float* __restrict__ batch_var) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, g = blockIdx.y;
+  const long long cnt = (long long)N * S;
+  const size_t base = ((size_t)g * N * C + c) * S, nstride = (size_t)C * S;
+  float mean, rstd;
+  if (training) {
+    double s1 = 0.0;
+    for (long long i = threadIdx.x; i < cnt; i += 256) s1 += x[base + (size_t)(i / S) * nstride + (size_t)(i % S)];
+    const double mu = block_sum_d(s1, red) / (double)cnt;
+    double s2 = 0.0;
+    for (long long i = threadIdx.x; i < cnt; i += 256) {
+      const double d = (double)x[base + (size_t)(i / S) * nstride + (size_t)(i % S)] - mu;
+      s2 += d * d;
+    }
+    const double var = block_sum_d(s2, red) / (double)cnt;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0 && batch_var) batch_var[(size_t)g * C + c] = (float)var;
+  } else {
+    mean = run_mean[(size_t)g * C + c];
+    rstd = 1.0f / sqrtf(run_var[(size_t)g * C + c] + eps);
+  }
+  if (threadIdx.x == 0) {
+    save_mean[(size_t)g * C + c] = mean;
+    save_rstd[(size_t)g * C + c] = rstd;
+  }
+  const float w = weight ? weight[(size_t)g * C + c] : 1.0f, b = bias ? bias[(size_t)g * C + c] : 0.0f;
+  const float sc = w * rstd, sh = b - mean * sc;
+  for (long long i = threadIdx.x; i < cnt; i += 256) {
+    const size_t o = base + (size_t)(i / S) * nstride + (size_t)(i % S);
+    y[o] = fmaf(x[o], sc, sh);
+  }
+}
+
+// dx = w rstd (dy - mean(dy) - xhat mean(dy xhat)) (training) | w rstd dy (eval);  dweight = sum dy xhat, dbias = sum dy
+__global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                            const float* __restrict__ weight, int N, int C, long long S,
+                                                            int training, float* __restrict__ dx, float* __restrict__ dweight,
+                                                            float* __restrict__ dbias) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, g = blockIdx.y;
+  const long long cnt = (long long)N * S;
+  const size_t base = ((size_t)g * N * C + c) * S, nstride = (size_t)C * S;
+  const float mean = save_mean[(size_t)g * C + c], rstd = save_rstd[(size_t)g * C + c];
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = threadIdx.x; i < cnt; i += 256) {
+    const size_t o = base + (size_t)(i / S) * nstride + (size_t)(i % S);
+    const float d = dy[o];
+    s1 += d;
+    s2 += (double)d * (double)((x[o] - mean) * rstd);
+  }
+  const double sdy = block_sum_d(s1, red), sdx = block_sum_d(s2, red);
+  if (threadIdx.x == 0) {
+    if (dweight) dweight[(size_t)g * C + c] = (float)sdx;
+    if (dbias) dbias[(size_t)g * C + c] = (float)sdy;
+  }
+  if (!dx) return;
+  const float w = weight ? weight[(size_t)g * C + c] : 1.0f;
+  const float k = w * rstd, m1 = training ? (float)(sdy / (double)cnt) : 0.f, m2 = training ? (float)(sdx / (double)cnt) : 0.f;
+  for (long long i = threadIdx.x; i < cnt; i += 256) {
+    const size_t o = base + (size_t)(i / S) * nstride + (size_t)(i % S);
+    const float xh = (x[o] - mean) * rstd;
+    dx[o] = k * (dy[o] - m1 - xh * m2);
+  }
+}
+
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -1154,6 +1243,29 @@ int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int 
   hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream, dcols, g,
                      rows, dx);
   return check_launch("col2im");
+}
+
+int hecka_batchnorm_fwd_f32(const float* x, int G, int N, int C, long long S, const float* weight, const float* bias,
+                            const float* run_mean, const float* run_var, int training, float eps, float* y,
+                            float* save_mean, float* save_rstd, float* batch_var, void* stream) {
+  clear_error();
+  if (!x || !y || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_fwd: null pointer%s");
+  if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_fwd: size out of range%s");
+  if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_fwd: eval mode needs running statistics%s");
+  hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
+                     run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var);
+  return check_launch("batchnorm_fwd");
+}
+
+int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_mean, const float* save_rstd,
+                            const float* weight, int G, int N, int C, long long S, int training, float* dx,
+                            float* dweight, float* dbias, void* stream) {
+  clear_error();
+  if (!dy || !x || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_bwd: null pointer%s");
+  if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_bwd: size out of range%s");
+  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
+                     weight, N, C, S, training, dx, dweight, dbias);
+  return check_launch("batchnorm_bwd");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,

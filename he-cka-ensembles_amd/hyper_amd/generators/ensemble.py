@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.module import GenModule, ParametersGroup, build_gen_module
+from ..layers.norm import _NormBuffers
 from ..util.collections import DefaultOrderedDict, flatten_keys
 
 AVAILABLE_GENERATORS = {}
@@ -53,6 +54,75 @@ class EnsembleParametersGroupGenerator(nn.Module):
         return torch.cat([v.index_select(0, idx).view(len(idx), -1) for v in self.fixed_parameters.values()], dim=1)
 
 
+class MemberBuffers:
+    """Running-statistics buffers of the selected members (what the reference passes as an OrderedDict of per-member
+    tensor lists, hyper/layers/generators/fixed.py:120-131): `bufs[name][i]` is member i's buffer (a view: in-place
+    updates reach the ensemble), `gather` / `update` are the vectorised forms the batched BatchNorm uses."""
+
+    def __init__(self, owner, idx):
+        self.owner, self.idx = owner, idx
+
+    def keys(self):
+        return list(self.owner.names)
+
+    def __getitem__(self, name):
+        store = getattr(self.owner, name)
+        return [store[i] for i in self.idx.tolist()]
+
+    def gather(self, name):
+        return getattr(self.owner, name).index_select(0, self.idx)
+
+    def update(self, name, value, factor):
+        store = getattr(self.owner, name)
+        store.index_copy_(0, self.idx, (1 - factor) * store.index_select(0, self.idx) + factor * value)
+
+
+class EnsembleBufferGroupGenerator(nn.Module):
+    """Per-member buffers (hyper/layers/generators/fixed.py:78-131).  Stored stacked as [size, *shape] so that one
+    tensor op serves all members; state_dict() / load_state_dict() use the reference's per-member keys
+    `mod-<member>-<name>`."""
+
+    def __init__(self, definition, fixed_size):
+        super().__init__()
+        if not isinstance(definition, ParametersGroup):
+            raise ValueError('an ensemble buffer generator needs a ParametersGroup (known buffer shapes)')
+        if isinstance(fixed_size, float) or fixed_size <= 0:
+            raise ValueError('Fixed size must be a non-negative integer')
+        self.definition, self.fixed_size = [definition], fixed_size
+        members = [definition.gen_initialized_params() for _ in range(fixed_size)]
+        self.names = list(members[0].keys())
+        for name in self.names:
+            self.register_buffer(name, torch.stack([m[name] for m in members]))
+        self.flat_size = sum(int(getattr(self, n)[0].numel()) for n in self.names)
+
+    def get_expected_input_size(self):
+        return self.fixed_size
+
+    def random(self, num, std=1.0, device=None):
+        fresh = EnsembleBufferGroupGenerator(self.definition[0], num)
+        return MemberBuffers(fresh.to(device) if device is not None else fresh, torch.arange(num, device=device))
+
+    def forward(self, codes):
+        return MemberBuffers(self, codes.long().ravel())
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for name in self.names:
+            store = getattr(self, name)
+            for ind in range(self.fixed_size):
+                destination['%smod-%d-%s' % (prefix, ind, name)] = store[ind] if keep_vars else store[ind].detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in self.names:
+            store = getattr(self, name)
+            for ind in range(self.fixed_size):
+                key = '%smod-%d-%s' % (prefix, ind, name)
+                if key in state_dict:
+                    with torch.no_grad():
+                        store[ind].copy_(state_dict[key])
+                elif strict:
+                    missing_keys.append(key)
+
+
 @register_generator('ensemble')
 class FixedEnsembleModel(nn.Module):
     def __init__(self, target, ensemble_size):
@@ -67,6 +137,8 @@ class FixedEnsembleModel(nn.Module):
             if isinstance(mod_def, dict):
                 generators[name] = nn.ModuleDict()
                 self._assign(mod_def, generators[name])
+            elif isinstance(mod_def, _NormBuffers):
+                generators[name] = EnsembleBufferGroupGenerator(mod_def, self.size)
             else:
                 generators[name] = EnsembleParametersGroupGenerator(mod_def, self.size)
 

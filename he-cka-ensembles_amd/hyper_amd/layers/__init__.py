@@ -2,3 +2,4 @@ from .module import (AVAILABLE_GEN_MODULES, Activation, Flatten, GenModule, Para
                      SequentialModule, build_gen_module, register_gen_module)
 from .linear import FinalLinear, Linear  # noqa: F401
 from .conv import Conv2d, FinalConv2d  # noqa: F401
+from .norm import BatchNorm1d, BatchNorm2d  # noqa: F401

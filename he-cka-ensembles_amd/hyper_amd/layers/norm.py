@@ -1,0 +1,142 @@
+"""Batched BatchNorm (hyper/layers/norm.py:12-46 `_NormAffine` / `_NormBuffers`, :49-127 `_NormBase`, :129-224
+`_BatchNorm.forward`, BatchNorm1d / BatchNorm2d).  The reference loops F.batch_norm over the ensemble members and stacks;
+here all members go through ONE launch (libhecka hecka_batchnorm_fwd_f32 / _bwd_f32: a workgroup per (member, channel))
+and the running statistics of the selected members are updated with a handful of [members, C] tensor ops."""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .module import GenModule, ParametersGroup
+
+
+class _NormAffine(ParametersGroup):
+    def __init__(self, num_features):
+        super().__init__(shapes=[('weight', (num_features,)), ('bias', (num_features,))])
+
+    def gen_initialized_params(self, dtype=None, device=None, gain=1):
+        params = self.gen_empty_params(dtype=dtype, device=device, requires_grad=True)
+        with torch.no_grad():
+            nn.init.ones_(params['weight'])
+            nn.init.zeros_(params['bias'])
+        return params
+
+
+class _NormBuffers(ParametersGroup):
+    def __init__(self, num_features):
+        super().__init__(shapes=[('mean', (num_features,)), ('var', (num_features,)), ('num_batches_tracked', (1,))])
+
+    def gen_initialized_params(self, dtype=None, device=None, gain=1):
+        params = self.gen_empty_params(dtype=dtype, device=device, requires_grad=False)
+        nn.init.zeros_(params['mean'])
+        nn.init.ones_(params['var'])
+        nn.init.zeros_(params['num_batches_tracked'])
+        return params
+
+
+class BatchedBatchNorm(torch.autograd.Function):
+    """y[m] = batch_norm(x[m], weight[m], bias[m]);  x [M,N,C,*], weight / bias [M,C] | None.  Returns (y, batch mean,
+    biased batch variance) - the statistics are by-products for the running averages and carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, run_mean, run_var, training, eps):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('hyper_amd BatchNorm needs fp32 GPU tensors; there is no CPU path')
+        x = x.contiguous()
+        M, N, C = x.shape[:3]
+        S = int(x[0, 0, 0].numel())
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        mean = torch.empty((M, C), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        var = torch.empty_like(mean) if training else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(_lib.lib().hecka_batchnorm_fwd_f32(
+            x.data_ptr(), M, N, C, S, ptr(w), ptr(b), ptr(run_mean), ptr(run_var), int(training), float(eps),
+            y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var), torch.cuda.current_stream().cuda_stream),
+            'batchnorm_fwd')
+        ctx.save_for_backward(x, mean, rstd, w)
+        ctx.cfg = (training, S, weight is not None, bias is not None)
+        if var is None:
+            var = mean.new_zeros(())
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, rstd, w = ctx.saved_tensors
+        training, S, has_w, has_b = ctx.cfg
+        M, N, C = x.shape[:3]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(mean) if has_w and ctx.needs_input_grad[1] else None
+        db = torch.empty_like(mean) if has_b and ctx.needs_input_grad[2] else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(_lib.lib().hecka_batchnorm_bwd_f32(
+            dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(w), M, N, C, S, int(training),
+            ptr(dx), ptr(dw), ptr(db), torch.cuda.current_stream().cuda_stream), 'batchnorm_bwd')
+        return dx, dw, db, None, None, None, None
+
+
+class _NormBase(GenModule):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, track=True):
+        super().__init__(track=track)
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        self.affine_module = _NormAffine(num_features) if affine else None
+        self.buffer_module = _NormBuffers(num_features) if track_running_stats else None
+
+    def is_generated(self):
+        return False
+
+    def define_generated_modules(self):
+        mod = super().define_generated_modules()
+        if self.affine:
+            mod['affine'] = self.affine_module.define_generated_modules()
+        if self.track_running_stats:      # fixed ensembles only (as in the reference)
+            mod['norm_buffer'] = self.buffer_module.define_generated_modules()
+        return mod
+
+    def _check_input_dim(self, input):
+        raise NotImplementedError
+
+    def extra_repr(self):
+        return '{num_features}, eps={eps}, momentum={momentum}, affine={affine}, ' \
+               'track_running_stats={track_running_stats}'.format(**self.__dict__)
+
+
+class _BatchNorm(_NormBase):
+    def forward(self, params, input):
+        self._check_input_dim(input)
+        weight = bias = None
+        if self.affine:
+            viewed = self.affine_module.from_flat(params['affine']['self'])
+            weight, bias = viewed['weight'], viewed['bias']
+        bufs = params['norm_buffer']['self'] if self.track_running_stats else None
+        bn_training = self.training or not self.track_running_stats
+        run_mean = run_var = None
+        if bufs is not None and not bn_training:
+            run_mean, run_var = bufs.gather('mean'), bufs.gather('var')
+        y, mean, var = BatchedBatchNorm.apply(input, weight, bias, run_mean, run_var, bn_training, self.eps)
+        if self.training and bufs is not None:
+            cnt = input.shape[1] * int(input[0, 0, 0].numel())
+            with torch.no_grad():
+                if self.momentum is None:   # cumulative average (num_batches_tracked is never advanced by the reference)
+                    factor = 1.0 / bufs.gather('num_batches_tracked')
+                else:
+                    factor = self.momentum
+                bufs.update('mean', mean, factor)
+                bufs.update('var', var * (cnt / max(cnt - 1, 1)), factor)
+        return self.track_feature(y), y
+
+
+class BatchNorm1d(_BatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 3 and input.dim() != 4:
+            raise ValueError('expected 3D or 4D input (got %dD input)' % input.dim())
+
+
+class BatchNorm2d(_BatchNorm):
+    def _check_input_dim(self, input):
+        if input.dim() != 5:
+            raise ValueError('expected 5D input (got %dD input)' % input.dim())

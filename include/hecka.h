@@ -159,6 +159,19 @@ int hecka_im2col_f32(const float* x, int Mx, int N, int C, int H, int W, int kh,
 int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
                      int pw, int dh, int dw, int rows, float* dx, void* stream);
 
+/* Batched BatchNorm (hyper/layers/norm.py:143-224 loops F.batch_norm over the members).
+ * x, y [G,N,C,S] (G = members, S = H*W or 1), weight / bias [G,C] (may be NULL), statistics per (member, channel).
+ * training: batch statistics (biased variance) normalise; save_mean / save_rstd [G,C] are kept for backward and
+ *   batch_var [G,C] (may be NULL) returns the biased variance for the caller's running-statistics update.
+ * eval (training = 0): run_mean / run_var [G,C] normalise.
+ * bwd: dx (may be NULL), dweight = sum dy xhat, dbias = sum dy ([G,C], may be NULL). */
+int hecka_batchnorm_fwd_f32(const float* x, int G, int N, int C, long long S, const float* weight, const float* bias,
+                            const float* run_mean, const float* run_var, int training, float eps, float* y,
+                            float* save_mean, float* save_rstd, float* batch_var, void* stream);
+int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_mean, const float* save_rstd,
+                            const float* weight, int G, int N, int C, long long S, int training, float* dx,
+                            float* dweight, float* dbias, void* stream);
+
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
  * hecka_colmean_f32; both given enables f16x3 (see HECKA_GEMM_AUTO). */

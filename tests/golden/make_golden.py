@@ -210,6 +210,52 @@ def run_lenet_step(dtype, tag):
     print('lenet_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']))
 
 
+CIFAR = {
+    'hyper': {'name': 'ensemble', 'ensemble_size': 3,
+              'target': {'name': 'resnet18', 'num_classes': 10, 'act': 'relu', 'planes': [8, 8, 16, 16, 32]}},
+    'method': {'name': 'repulsive_kernel', 'num': 3, 'gamma': 1.0, 'beta_ind': 5.0, 'warmup': 10,
+               'model_kernel': layers(he(eps=0.001, arc_eps=0.001, use_exp=True),
+                                      {'name': 'list', 'weights': [0.0, 0.15, 0.25, 0.35, 0.4, 0.45, 0.5, 0.0001],
+                                       'normalize': False}),
+               'ind_loss': {'name': 'cross_entropy'}},
+}
+
+
+def run_resnet_step(dtype, tag):
+    """One training step of BASELINE configs[2] (configs/cifar10/base.yml + ens/he-lin.yml: ResNet18 ensemble with
+    batched Conv2d / BatchNorm2d, HE on the eight tracked features) with the REAL reference; narrow planes, three
+    members, a batch of 6 16x16 images.  Also records the BatchNorm running statistics after the step."""
+    import hyper.target.resnet  # noqa: F401  (registers `resnet18`)
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    torch.manual_seed(41)
+    hyper = build_generator(CIFAR['hyper']).to(dtype)
+    method = build_method(CIFAR['method']).to(dtype)
+    gen = torch.Generator().manual_seed(8)
+    X = torch.randn(6, 3, 16, 16, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 10, (6,), generator=gen)
+    rec = {'config': json.dumps(CIFAR), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 20}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.clone().numpy()
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(3)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=20)
+    track['loss'].backward()
+    rec.update({'loss': track['loss'].detach().numpy(), 'ind_loss': track['ind_loss'].detach().numpy(),
+                'ind_rep_loss': track['ind_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy(),
+                'feat_keys': json.dumps(list(track['feats_ind'].keys())),
+                'feat_shapes': json.dumps([list(v.shape) for v in track['feats_ind'].values()])})
+    for k, v in hyper.state_dict().items():
+        if '.norm_buffer.' in k:
+            rec['after:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'resnet_train_step_%s.npz' % tag), **rec)
+    print('resnet_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']),
+          list(track['feats_ind'].keys()))
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -244,6 +290,7 @@ def main():
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         run_train_step(dtype, tag)
         run_lenet_step(dtype, tag)
+    run_resnet_step(torch.float64, 'f64')
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)

@@ -400,3 +400,78 @@ def test_lenet_train_step_matches_reference_golden():
     assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
     for k, v in hyper.named_parameters():
         assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 5e-5, k
+
+
+@pytest.mark.parametrize('shape,affine,training', [((3, 6, 5, 7, 4), True, True), ((2, 9, 4, 3, 3), False, True),
+                                                    ((3, 6, 5, 7, 4), True, False), ((4, 10, 12), True, True)])
+def test_batched_batchnorm_matches_oracle(shape, affine, training):
+    """hecka_batchnorm_fwd/bwd (one launch for all members) vs the per-member F.batch_norm loop of norm.py:206-222
+    (oracle.layers_ref, fp64 CPU): output, dx, dweight, dbias and the running statistics after the call."""
+    from oracle import layers_ref as LR
+    from hyper_amd.layers.norm import BatchedBatchNorm
+    dev = _dev()
+    g = torch.Generator().manual_seed(sum(shape) + affine)
+    M, N, C = shape[:3]
+    x64 = (torch.randn(*shape, generator=g, dtype=torch.float64) * 1.7 + 0.6).requires_grad_(True)
+    w64 = (torch.randn(M, C, generator=g, dtype=torch.float64) + 1.0).requires_grad_(True) if affine else None
+    b64 = torch.randn(M, C, generator=g, dtype=torch.float64).requires_grad_(True) if affine else None
+    rm64 = torch.randn(M, C, generator=g, dtype=torch.float64) * 0.1
+    rv64 = torch.rand(M, C, generator=g, dtype=torch.float64) + 0.5
+    up = torch.randn(*shape, generator=g, dtype=torch.float64)
+    x = x64.detach().float().to(dev).requires_grad_(True)
+    w = w64.detach().float().to(dev).requires_grad_(True) if affine else None
+    b = b64.detach().float().to(dev).requires_grad_(True) if affine else None
+    rm, rv = rm64.float().to(dev), rv64.float().to(dev)
+    y, mean, var = BatchedBatchNorm.apply(x, w, b, None if training else rm, None if training else rv, training, 1e-5)
+    (y * up.float().to(dev)).sum().backward()
+    yo = LR.batched_batch_norm(x64, w64, b64, rm64, rv64, training, 0.1, 1e-5)   # updates rm64 / rv64 in place
+    (yo * up).sum().backward()
+    assert _relerr(y.detach().cpu().numpy(), yo.detach().numpy()) <= RTOL
+    assert _relerr(x.grad.cpu().numpy(), x64.grad.numpy()) <= RTOL
+    if affine:
+        assert _relerr(w.grad.cpu().numpy(), w64.grad.numpy()) <= RTOL
+        assert _relerr(b.grad.cpu().numpy(), b64.grad.numpy()) <= RTOL
+    if training:
+        cnt = x64[0, :, 0].numel()
+        assert _relerr((0.9 * rm + 0.1 * mean).cpu().numpy(), rm64.numpy()) <= RTOL
+        assert _relerr((0.9 * rv + 0.1 * var * cnt / (cnt - 1)).cpu().numpy(), rv64.numpy()) <= RTOL
+
+
+def test_resnet_train_step_matches_reference_golden():
+    """BASELINE configs[2] shape (CIFAR ResNet18 ensemble with HE-CKA on the eight tracked block features; narrow
+    planes, 3 members): one training step through hyper_amd's FixedEnsembleModel -> batched Conv2d / BatchNorm2d /
+    Linear -> RepulsiveKernel -> backward against the step the REAL reference produced
+    (tests/golden/resnet_train_step_f64.npz): predictions, losses, every parameter gradient, and the BatchNorm
+    running statistics after the step (state-dict keys `...norm_buffer.self.mod-<member>-<name>`)."""
+    import json
+    import os
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'resnet_train_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    ref_keys = sorted(k[2:] for k in z.files if k.startswith('w:'))
+    assert sorted(hyper.state_dict().keys()) == ref_keys
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    track = hyper(params=list(range(3)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    assert list(track['feats_ind'].keys()) == json.loads(str(z['feat_keys']))
+    assert [list(v.shape) for v in track['feats_ind'].values()] == json.loads(str(z['feat_shapes']))
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
+    track['loss'].backward()
+    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 2e-5
+    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
+    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+    after = hyper.state_dict()
+    for k in z.files:
+        if k.startswith('after:'):
+            assert _relerr(after[k[6:]].cpu().numpy(), z[k]) <= 2e-5 or np.abs(z[k]).max() == 0, k
