@@ -1,6 +1,8 @@
 // libhecka: HIP kernels (gfx950) + C-ABI for the HE-CKA diversity-loss hot path.
 // See include/hecka.h for the contract of every entry point and DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -182,8 +184,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_kernel(GemmOperands g
 // Workgroup -> (member, tile).  Workgroup w runs on XCD w % 8 and each XCD has its own L2: with M % 8 == 0 all
 // tiles of a member go to ONE XCD, back to back, so the member's panels are read from HBM once and shared through
 // that L2 (otherwise every XCD streams every member: measured 15 % slower at P = 8192).
-__device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& tl) {
-  const int w = blockIdx.x;
+__device__ __forceinline__ void member_tile_w(int w, int per, int xcd_map, int& m, int& tl) {
   if (xcd_map) {
     const int slot = w >> 3;
     m = (slot / per) * 8 + (w & 7);
@@ -192,6 +193,9 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
     m = w / per;
     tl = w % per;
   }
+}
+__device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& tl) {
+  member_tile_w(blockIdx.x, per, xcd_map, m, tl);
 }
 
 // Split-precision variants of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands
@@ -220,16 +224,15 @@ struct CenterProX6 {
 };
 
 template <int SCHEME>
-__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
-                                                                     const float* __restrict__ sbar,
-                                                                     const float* __restrict__ xmax,
-                                                                     float* __restrict__ C, float* __restrict__ cvec,
-                                                                     int B, int P, int ntile, int xcd_map) {
+__device__ __forceinline__ void gram_center_x6_body(const float* __restrict__ X, const float* __restrict__ sbar,
+                                                    const float* __restrict__ xmax, float* __restrict__ C,
+                                                    float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
+                                                    int w) {
   using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME>;
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
   int m, rem;
-  member_tile(ntile * (ntile + 1) / 2, xcd_map, m, rem);
+  member_tile_w(w, ntile * (ntile + 1) / 2, xcd_map, m, rem);
   int I = 0;
   while (rem >= ntile - I) {
     rem -= ntile - I;
@@ -265,6 +268,50 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float
     Cm[(size_t)(row0 + lr) * B + col0 + lc] = v + cB[lc];
     if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v + cA[lr];
   });
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
+                                                                     const float* __restrict__ sbar,
+                                                                     const float* __restrict__ xmax,
+                                                                     float* __restrict__ C, float* __restrict__ cvec,
+                                                                     int B, int P, int ntile, int xcd_map) {
+  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, (int)blockIdx.x);
+}
+
+// All tracked layers in ONE launch.  A layer's Gram is M * 10 equal workgroups (B = 512) on 512 resident slots: launched
+// alone it runs 1.25 "rounds" in the time of 2.  With every layer in one grid, deepest layer first, the slots freed by one
+// layer's last workgroups go to the next layer's first ones and only the launch's very end is ragged.
+constexpr int kMaxGramLayers = 16;
+struct GramLayerArgs {
+  const float* X;
+  const float* sbar;
+  const float* xmax;
+  float* C;
+  float* cvec;
+  int P;
+  int wg_end;   // first workgroup of the next layer
+};
+struct GramMultiArgs {
+  GramLayerArgs l[kMaxGramLayers];
+  int L;
+};
+
+template <int SCHEME>
+__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
+  const int w = blockIdx.x;
+  int li = 0, w0 = 0;
+  while (li + 1 < a.L && w >= a.l[li].wg_end) {
+    w0 = a.l[li].wg_end;
+    ++li;
+  }
+  // (kernel-argument struct indexed with a runtime index: copy the selected layer's fields through scalar selects)
+  const float* X = a.l[0].X; const float* sbar = a.l[0].sbar; const float* xmax = a.l[0].xmax;
+  float* C = a.l[0].C; float* cvec = a.l[0].cvec; int P = a.l[0].P;
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) { X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P; }
+  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -351,6 +398,127 @@ __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, co
       W[(size_t)i * g.colsB + n] = w;
     }
   });
+}
+
+__device__ __forceinline__ float block_sum_f(float v, float* red) {   // 256-thread workgroups
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float t = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return t;
+}
+
+// Streaming form of combine for the common shape (Mb = 64 members, Ma = 32 or 64 rows, B % 64 == 0): K is only 64
+// deep, so the LDS-tiled GEMM core spends its time filling and draining.  Here A (Ma x 64) sits in LDS as MFMA A
+// fragments, every wave streams 64-column chunks of C straight from HBM into MFMA B fragments (lane (h, j) loads
+// C[2 ks + h][n0 + 2 j .. + 1]: 256 contiguous bytes per half-wave, no LDS round trip), 32 k-steps x RB x 2
+// v_mfma_f32_32x32x2_f32 per chunk, and the epilogue adds the gamma terms and stores float2.  HBM-bound: reads C once,
+// writes W once.
+template <int RB>
+__global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __restrict__ A, const float* __restrict__ C,
+                                                                const float* __restrict__ gamma, int B, int detach_diag,
+                                                                float* __restrict__ W) {
+  __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]
+  __shared__ float sG[4][32 * RB];   // per wave: gamma[:, a] of the chunk's Gram row a
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, j = lane & 31;
+  for (int e = t; e < 32 * RB * 64; e += 256) {
+    const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
+    sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
+  }
+  __syncthreads();
+  const long long N = (long long)B * B;
+  const int strips = B / 64;
+  const long long nchunks = N / 64;
+  // buffer addressing: one per-lane byte offset per chunk + scalar row offsets (no 64-bit pointers kept per row)
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C), 0, (int)(64 * N * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(W, 0, (int)(32 * RB * N * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gamma), 0, 32 * RB * B * 4, 0x00020000);
+  const unsigned rowN = (unsigned)N * 4u;
+  // chunk c -> Gram row a = c / strips, columns b0 = 64 (c % strips); the B fragments of the wave's NEXT chunk are
+  // loaded while the 128 MFMAs of the current one issue (two register sets)
+  const long long cstep = (long long)gridDim.x * 4;
+  long long c = (long long)blockIdx.x * 4 + wave;
+  f32x2 bf[2][32];
+  auto load_b = [&](auto SET, long long cc) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const unsigned n0 = (unsigned)(cc / strips) * B + (unsigned)(cc % strips) * 64;
+    const unsigned vC = (unsigned)h * rowN + (n0 + 2 * j) * 4u;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+      bf[S][ks] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsC, (int)vC, (int)(2 * ks * rowN), 0));
+  };
+  auto chunk = [&](auto SET, long long cc) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const int a = (int)(cc / strips), b0 = (int)(cc % strips) * 64;
+    const unsigned n0 = (unsigned)a * B + b0;
+    if (lane < 32 * RB) sG[wave][lane] = gamma[(size_t)lane * B + a];
+    if (cc + cstep < nchunks) load_b(std::integral_constant<int, 1 - S>{}, cc + cstep);
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[rb][cb][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const float af = sA[ks][rb][lane];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[S][ks][cb], acc[rb][cb], 0, 0, 0);
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int d0 = a - b0 - 2 * j;   // column offset of the Gram diagonal inside this lane's pair (0 or 1), if any
+    const unsigned vW = 4u * h * rowN + (n0 + 2 * j) * 4u;
+    const unsigned vG = (4u * h * B + b0 + 2 * j) * 4u;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ib = rb * 32 + (q & 3) + 8 * (q >> 2);   // row i = ib + 4 h
+        const f32x2 gc = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsG, (int)vG, ib * B * 4, 0));
+        const float gr = sG[wave][ib + 4 * h];
+        f32x2 w = {2.f * acc[rb][0][q] + gr - gc[0], 2.f * acc[rb][1][q] + gr - gc[1]};
+        if (detach_diag) {
+          if (d0 == 0) w[0] = 0.f;
+          if (d0 == 1) w[1] = 0.f;
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rsW, (int)vW, (int)(ib * rowN), 0);
+      }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (c < nchunks) load_b(std::integral_constant<int, 0>{}, c);
+  while (c < nchunks) {
+    chunk(std::integral_constant<int, 0>{}, c);
+    c += cstep;
+    if (c >= nchunks) break;
+    chunk(std::integral_constant<int, 1>{}, c);
+    c += cstep;
+  }
+}
+
+// Upper bound of max |W_i| for the fp16-split dX GEMM, from quantities that already exist:
+//   |W_i| <= 2 sum_j |A_ij| ||C_j||_F + 2 max_b |gamma_ib|        (W_i = 2 sum_j A_ij C_j + gamma_i 1^T - 1 gamma_i^T)
+// A power-of-two scale taken from a bound that is loose by 2^k costs k bits of the low plane's subnormal floor only
+// (absolute error 2^-39+k of the bound): replaces a full pass over W.  One workgroup per row i.
+__global__ __launch_bounds__(256) void wbound_kernel(const float* __restrict__ A, const float* __restrict__ nsq,
+                                                     const float* __restrict__ gamma, int Mb, int B,
+                                                     float* __restrict__ wbound) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  float s = 0.f, g = 0.f;
+  for (int jj = threadIdx.x; jj < Mb; jj += 256) s += fabsf(A[(size_t)i * Mb + jj]) * sqrtf(fmaxf(nsq[jj], 0.f));
+  for (int b = threadIdx.x; b < B; b += 256) g = fmaxf(g, fabsf(gamma[(size_t)i * B + b]));
+  const float st = block_sum_f(s, red);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+  __syncthreads();
+  if (threadIdx.x == 0) wbound[i] = 2.f * st + 2.f * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // wmax[i] = max |W_i| over a row of n floats, for the fp16-split dX GEMM.  A separate pass right behind combine (W
@@ -549,12 +717,13 @@ __device__ __forceinline__ double block_sum_head(double v, double* red) {
 }
 
 // forward: one workgroup (the sum over all pairs is taken in a fixed order: deterministic)
-__global__ __launch_bounds__(kHeadThreads) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
-                                                       int Ma, int Mb, HeadCfg c, float* __restrict__ val,
-                                                       float* __restrict__ sum_out, double scale) {
-  __shared__ double red[kHeadThreads / 64];
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                           int Ma, int Mb, HeadCfg c, float* __restrict__ val,
+                                                           float* __restrict__ sum_out, double scale) {
+  __shared__ double red[THREADS / 64];
   double acc = 0.0;
-  for (int e = threadIdx.x; e < Ma * Mb; e += kHeadThreads) {
+  for (int e = threadIdx.x; e < Ma * Mb; e += THREADS) {
     const int i = e / Mb, j = e - i * Mb;
     const double di = sqrt((double)nsq[c.row_offset + i]) + c.eps, dj = sqrt((double)nsq[j]) + c.eps;
     double v, dv;
@@ -562,8 +731,15 @@ __global__ __launch_bounds__(kHeadThreads) void head_fwd_kernel(const float* __r
     if (val) val[e] = (float)v;
     if (!(c.remove_diag && j == c.row_offset + i)) acc += v;
   }
-  const double tot = block_sum_head(acc, red);
-  if (sum_out && threadIdx.x == 0) *sum_out = (float)(tot * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (sum_out && threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < THREADS / 64; ++w) tot += red[w];   // fixed order: deterministic
+    *sum_out = (float)(tot * scale);
+  }
 }
 
 // backward: rows are independent - one wave per row i, four rows per workgroup, no LDS.
@@ -616,15 +792,6 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __r
 //     kind 1 cossim: K'_ab = G_ab / sqrt(G_aa G_bb)                      (kernels.py:145-169)
 //     kind 2 rbf   : d_ab = -2 G_ab + G_aa + G_bb, K'_ab = exp(-d_ab / (2 h_m))   (kernels.py:198-286)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_f(float v, float* red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const float t = red[0] + red[1] + red[2] + red[3];
-  __syncthreads();
-  return t;
-}
 
 // One workgroup per (row a, member m): C[a,:] = K'[a,:] - mean (center) or K'[a,:]; rmean, gdiag side outputs.
 __global__ __launch_bounds__(256) void gram_transform_kernel(const float* __restrict__ G, int B, int kind,
@@ -912,7 +1079,9 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float* __restr
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
-  long long want = (1024 + tiles - 1) / tiles;        // ~4 workgroups per CU in flight
+  const char* e = getenv("HECKA_PAIRWISE_WGS");
+  // one workgroup per CU: 256 partial [Ma,Mb] slabs (4 MiB at M = 64) instead of 1024 - measured 31.7 vs 44.0 us
+  long long want = ((e ? atoi(e) : 256) + tiles - 1) / tiles;
   long long maxs = (ktiles + 7) / 8;                  // at least 8 K-tiles (256 k) per workgroup
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -993,6 +1162,38 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
   return check_launch("gram_center");
 }
 
+int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
+                                int B, const int* P, float* const* C, float* const* cvec, void* stream) {
+  clear_error();
+  if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
+  if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
+  if (M <= 0 || B <= 0 || B % 128 != 0) return fail(HECKA_EINVAL, "gram_center_multi: needs B %% 128 == 0 (B = %lld)%s", "", B);
+  if (g_gemm_mode == HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "gram_center_multi: not available in HECKA_GEMM_FP32 mode%s");
+  const int ntile = B / 128, per = M * (ntile * (ntile + 1) / 2);
+  bool have_max = xmax != nullptr;
+  GramMultiArgs a;
+  a.L = L;
+  long long wg = 0;
+  for (int i = 0; i < L; ++i) {
+    if (!X[i] || !sbar[i] || !C[i] || !cvec[i]) return fail(HECKA_EINVAL, "gram_center_multi: null layer pointer%s");
+    if (P[i] <= 0 || P[i] % 16 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * 4 >= (1ll << 32))
+      return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)%s", "", P[i]);
+    if (i > 0 && P[i] > P[i - 1]) return fail(HECKA_EINVAL, "gram_center_multi: layers must come deepest (largest P) first%s");
+    have_max = have_max && xmax[i] != nullptr;
+    wg += per;
+    a.l[i] = GramLayerArgs{X[i], sbar[i], xmax ? xmax[i] : nullptr, C[i], cvec[i], P[i], (int)wg};
+  }
+  for (int i = L; i < kMaxGramLayers; ++i) a.l[i] = a.l[L - 1];
+  if (wg > 0x7fffffffLL) return fail(HECKA_EINVAL, "gram_center_multi: grid too large%s");
+  hipStream_t st = (hipStream_t)stream;
+  const int xcd = (int)(M % 8 == 0);
+  if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
+    hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+  else
+    hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+  return check_launch("gram_center_multi");
+}
+
 size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {
   if (Ma <= 0 || Mb <= 0 || K <= 0) return 0;
   return (size_t)pairwise_nsplit(Ma, Mb, K) * Ma * Mb * sizeof(float);
@@ -1062,6 +1263,20 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   const bool full = vec && (Ma % 64 == 0) && (N % 128 == 0) && (Mb % kBK == 0);
   unsigned* wm = reinterpret_cast<unsigned*>(wmax);
   if (wm && hipMemsetAsync(wm, 0, (size_t)Ma * sizeof(unsigned), st) != hipSuccess) return check_launch("combine (memset)");
+  if (mode == 1 && Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && aligned16(A) && aligned16(C) && aligned16(gamma) &&
+      aligned16(W) && !getenv("HECKA_COMBINE_TILED")) {
+    const char* ge = getenv("HECKA_COMBINE_WGS");
+    const unsigned nwg = (unsigned)std::min<long long>(N / 256, ge ? atoi(ge) : 512);
+    if (Ma == 64)
+      hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W);
+    else
+      hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W);
+    if (wm) {
+      const int chunks = (int)(N >= (1 << 16) ? 16 : 1);
+      hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, Ma), dim3(256), 0, st, W, N, chunks, wm);
+    }
+    return check_launch("combine");
+  }
 #define HECKA_COMBINE(V, MD, F) \
   hipLaunchKernelGGL((combine_kernel<V, MD, F>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN)
   if (mode == 1) {
@@ -1085,6 +1300,15 @@ int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma
                       float* W, float* wmax, void* stream) {
   if (B <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
   return combine_impl(A, C, gamma, Ma, Mb, (long long)B * B, B, detach_diag, W, wmax, stream, 1);
+}
+
+int hecka_wbound_f32(const float* A, const float* nsq, const float* gamma, int Ma, int Mb, int B, float* wbound,
+                     void* stream) {
+  clear_error();
+  if (!A || !nsq || !gamma || !wbound) return fail(HECKA_EINVAL, "wbound: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || B <= 0) return fail(HECKA_EINVAL, "wbound: non-positive size%s");
+  hipLaunchKernelGGL(wbound_kernel, dim3(Ma), dim3(256), 0, (hipStream_t)stream, A, nsq, gamma, Mb, B, wbound);
+  return check_launch("wbound");
 }
 
 int hecka_rowmix_f32(const float* A, const float* V, int Ma, int Mb, long long K, float* out, void* stream) {
@@ -1129,7 +1353,11 @@ int hecka_head_fwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   if (!S || !nsq || (!val && !sum_out)) return fail(HECKA_EINVAL, "head_fwd: null pointer%s");
   HeadCfg c;
   if (int rc = head_cfg(c, kind, s, eps, arc_eps, flags, row_offset, Ma, Mb)) return rc;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(1), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
+  // one workgroup (fixed-order sum); 1024 threads when the matrix is big enough to use them (4 pairs each at M = 64)
+  if ((long long)Ma * Mb >= 2048)
+    hipLaunchKernelGGL(head_fwd_kernel<1024>, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<kHeadThreads>, dim3(1), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, val, sum_out, scale);
   return check_launch("head_fwd");
 }
 

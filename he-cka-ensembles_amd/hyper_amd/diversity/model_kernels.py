@@ -141,17 +141,24 @@ class _PairwiseHead(BaseModelKernel):
     def _spec(self):
         return None
 
-    def _values(self, feats, track, reduce=None):
+    def _values(self, feats, track, reduce=None, pre=None):
         """Fast path only: value matrix [M,M] (reduce=None) or the reduced scalar."""
         fk = self.feature_kernel
-        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce, fk.gram_spec())
+        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce, fk.gram_spec(), pre)
         track['gram'] = gram
         return out
 
-    def reduced(self, feats, track, reduce):
+    def shares_gram_launch(self):
+        """This layer's centred linear Gram may come from the all-layers launch (ops.centered_gram_multi)."""
+        if self._spec() is None:
+            return False
+        gs = self.feature_kernel.gram_spec()
+        return gs is not None and gs.kind == ops.GRAM_LINEAR
+
+    def reduced(self, feats, track, reduce, pre=None):
         """mean / sum of this layer's kernel values as a 0-dim tensor (what ModelLayersKernel needs)."""
         if self._spec() is not None:
-            return self._values(feats, track, reduce)
+            return self._values(feats, track, reduce, pre)
         vals = self(None, feats, None, track)
         return vals.mean() if reduce == 'mean' else vals.sum()
 
@@ -266,12 +273,12 @@ class ModelLayersKernel(BaseModelKernel):
             return model_grams.sum()
         return model_grams
 
-    # Layers are independent until the final weighted sum, so on the GPU each layer's kernel chain is
-    # enqueued on its own HIP stream (round-robin over `num_streams`): the tail of one layer's Gram launch
-    # and its small [M,M] kernels overlap with another layer's MFMA work.  Autograd replays every node on
-    # the stream it ran on in forward, so the backward overlaps the same way.  0/1 = everything in order on
-    # the current stream.
-    num_streams = int(os.environ.get('HECKA_LAYER_STREAMS', '4'))
+    # Layers are independent until the final weighted sum.  HECKA_LAYER_STREAMS = n > 1 enqueues each layer's kernel
+    # chain on its own HIP stream (round-robin over n; autograd replays every node on its forward stream).  That paid
+    # (+8 %) while every layer launched its own Gram GEMM - a second layer filled the GPU's ragged second scheduling
+    # round - and stopped paying once all layers' Grams became ONE launch (ops.centered_gram_multi): measured
+    # 225.9 evals/s in order on one stream vs 223.6 on four.  Default: everything in order on the current stream.
+    num_streams = int(os.environ.get('HECKA_LAYER_STREAMS', '1'))
     # (stream priorities were tried: with more streams than hardware queues a high-priority stream starved the rest
     # - 0.6 evals/s - so all layer streams keep the default priority)
     _streams = {}
@@ -282,10 +289,23 @@ class ModelLayersKernel(BaseModelKernel):
             ModelLayersKernel._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
         return ModelLayersKernel._streams[key]
 
-    def _layer_value(self, kern, params, feat, pred, ltrack):
+    def _layer_value(self, kern, params, feat, pred, ltrack, pre=None):
         if self.reduction in ('mean', 'sum') and isinstance(kern, _PairwiseHead):
-            return kern.reduced(feat, ltrack, self.reduction)   # reduced inside the head kernel
+            return kern.reduced(feat, ltrack, self.reduction, pre)   # reduced inside the head kernel
         return self.apply_reduction(kern(params, feat, pred, ltrack))
+
+    def _shared_grams(self, kerns, flist):
+        """Centred Grams of ALL layers from one launch (None when some layer is not on the fused linear path, or the
+        shapes are not interior): a single layer's Gram grid leaves most of the GPU's second scheduling round empty."""
+        if os.environ.get('HECKA_MULTI_GRAM', '1') == '0' or self.reduction not in ('mean', 'sum'):
+            return None
+        if not all(isinstance(k, _PairwiseHead) and k.shares_gram_launch() for k in kerns):
+            return None
+        Xs = [ops._features_f32(FeatureKernel.flatten(f)) for f in flist]
+        if not ops.multi_gram_eligible(Xs) or any(x.requires_grad and x.dtype != f.dtype for x, f in zip(Xs, flist)):
+            return None
+        with torch.no_grad():
+            return ops.centered_gram_multi([x.detach() for x in Xs])
 
     def forward(self, params, feats, pred, track):
         total = len(feats)
@@ -297,6 +317,7 @@ class ModelLayersKernel(BaseModelKernel):
         flist = list(feats.values())
         kerns = [self.layer_kernel[i] if self.different_kernels else self.layer_kernel for i in range(total)]
         nstream = min(self.num_streams, total) if flist[0].is_cuda else 0
+        pre = self._shared_grams(kerns, flist) if flist[0].is_cuda else None
         values = []
         if nstream > 1:
             main = torch.cuda.current_stream(flist[0].device)
@@ -311,7 +332,11 @@ class ModelLayersKernel(BaseModelKernel):
                 feat = flist[index]
                 st = streams[slot[index]]
                 with torch.cuda.stream(st):
-                    v = self._layer_value(kerns[index], params, feat, pred, layer_track[index])
+                    if pre is not None:
+                        for t in pre[index]:
+                            t.record_stream(st)
+                    v = self._layer_value(kerns[index], params, feat, pred, layer_track[index],
+                                          pre[index] if pre is not None else None)
                     v.record_stream(main)
                     g = layer_track[index].get('gram')
                     if g is not None:
@@ -321,11 +346,21 @@ class ModelLayersKernel(BaseModelKernel):
                 main.wait_stream(st)
         else:
             for index, feat in enumerate(flist):
-                values.append(self._layer_value(kerns[index], params, feat, pred, layer_track[index]))
-        out = None
-        for index, value in enumerate(values):
-            term = self.layer_weighting.get_weight(index, total) * value
-            out = term if out is None else out + term
+                values.append(self._layer_value(kerns[index], params, feat, pred, layer_track[index],
+                                                pre[index] if pre is not None else None))
+        weights = [self.layer_weighting.get_weight(index, total) for index in range(total)]
+        if all(v.ndim == 0 for v in values) and not any(isinstance(w, torch.Tensor) for w in weights):
+            # host-float weights and scalar layer values: one stack + one dot instead of 2 L tiny kernels (and 2 L more
+            # in backward); same sum order as the reference's loop up to fp32 rounding of the partial sums
+            key = (tuple(float(w) for w in weights), str(values[0].device), values[0].dtype)
+            if getattr(self, '_wcache', (None,))[0] != key:
+                self._wcache = (key, torch.tensor(key[0], device=values[0].device, dtype=values[0].dtype))
+            out = torch.dot(torch.stack(values), self._wcache[1])
+        else:
+            out = None
+            for index, value in enumerate(values):
+                term = weights[index] * value
+                out = term if out is None else out + term
         track['layer_track'] = layer_track
         return out
 

@@ -2,6 +2,8 @@
 
 PyTorch is plumbing here: it owns the device memory and the stream; all arithmetic on [M,B,P]
 and [M,B,B] tensors happens in the HIP kernels."""
+import os
+
 import torch
 
 from . import _lib
@@ -38,6 +40,33 @@ def _check_features(X):
         raise RuntimeError('expected features of shape [members, samples, features]')
 
 
+class _GemmChain:
+    """The two big GEMMs (centred Gram, dX) each fill the whole GPU, so running two of them side by side from
+    different layer streams only stretches both.  Every big-GEMM launch therefore waits for the previous one (an event
+    chain across the layer streams, enqueue order); the small HBM-bound kernels of other layers still overlap them.
+    HECKA_GEMM_CHAIN=0 disables the chain."""
+    enabled = os.environ.get('HECKA_GEMM_CHAIN', '1') != '0'
+    last = {}
+
+    @classmethod
+    def enter(cls, device):
+        if not cls.enabled:
+            return None
+        cur = torch.cuda.current_stream(device)
+        prev = cls.last.get(device.index)
+        if prev is not None and prev[1] != cur.cuda_stream:
+            cur.wait_event(prev[0])
+        return cur
+
+    @classmethod
+    def leave(cls, device, cur):
+        if cur is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        cls.last[device.index] = (ev, cur.cuda_stream)
+
+
 def centered_gram(X, return_xmax=False):
     """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd.
     `return_xmax` adds xmax [M] = max |X[m]| (a by-product of the column-mean pass) for gram_backward: with it the
@@ -50,8 +79,52 @@ def centered_gram(X, return_xmax=False):
     cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
     st = _stream()
     _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
+    gate = _GemmChain.enter(X.device)
     _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), _p(xmax), M, B, P, _p(C), _p(cvec), st), 'gram_center')
+    _GemmChain.leave(X.device, gate)
     return (C, cvec, xmax) if return_xmax else (C, cvec)
+
+
+def multi_gram_eligible(Xs):
+    """All layers can share ONE centred-Gram launch (hecka_gram_center_multi_f32): fp32 GPU features with the same
+    members and samples, B % 128 == 0, every P % 16 == 0, at most 16 layers, split-precision GEMM mode."""
+    if not 2 <= len(Xs) <= 16:
+        return False
+    M, B = Xs[0].shape[0], Xs[0].shape[1]
+    for X in Xs:
+        if not (X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.shape[0] == M and X.shape[1] == B):
+            return False
+        if X.shape[2] % 16 or B * X.shape[2] * 4 >= 2 ** 32:
+            return False
+    return B % 128 == 0 and _lib.lib().hecka_get_gemm_mode() != 1
+
+
+def centered_gram_multi(Xs):
+    """[X_l [M,B,P_l]] -> [(C_l, cvec_l, xmax_l)]: the column-mean passes, then every layer's centred Gram in one
+    launch, deepest layer first (no autograd)."""
+    import ctypes
+    L = _lib.lib()
+    M, B = Xs[0].shape[0], Xs[0].shape[1]
+    st = _stream()
+    dev = Xs[0].device
+    order = sorted(range(len(Xs)), key=lambda i: -Xs[i].shape[2])
+    Xs = [X.contiguous() for X in Xs]
+    out = []
+    for X in Xs:
+        P = X.shape[2]
+        sbar = torch.empty((M, P), device=dev, dtype=torch.float32)
+        xmax = torch.empty((M,), device=dev, dtype=torch.float32)
+        C = torch.empty((M, B, B), device=dev, dtype=torch.float32)
+        cvec = torch.empty((M, B), device=dev, dtype=torch.float32)
+        _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
+        out.append((C, cvec, xmax, sbar))
+    n = len(Xs)
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
+    _lib.check(L.hecka_gram_center_multi_f32(
+        n, ptrs([Xs[i] for i in order]), ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
+        (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]), ptrs([out[i][0] for i in order]),
+        ptrs([out[i][1] for i in order]), st), 'gram_center_multi')
+    return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
 
 
 def pairwise_inner(Ca, Cb=None):
@@ -67,9 +140,11 @@ def pairwise_inner(Ca, Cb=None):
     return S
 
 
-def gram_backward(A, C, cvec, X, detach_diag, xmax=None):
+def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None):
     """dX_i = (dC_i + dC_i^T, diag masked) X_i with dC_i = sum_j A[i,j] C[j].
-    xmax: [Ma] max |X_i| from centered_gram(return_xmax=True), or None."""
+    xmax: [Ma] max |X_i| from centered_gram(return_xmax=True), or None.
+    nsq: [Mb] squared Frobenius norms of C (diag of the pairwise matrix), or None: with it the bound on |W| for the
+    fp16-split dX GEMM comes from hecka_wbound_f32 instead of a pass over W."""
     L = _lib.lib()
     Ma, Mb = A.shape
     B, P = X.shape[1], X.shape[2]
@@ -79,8 +154,12 @@ def gram_backward(A, C, cvec, X, detach_diag, xmax=None):
     dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), st), 'coef_gamma')
     wmax = torch.empty((Ma,), device=X.device, dtype=torch.float32) if xmax is not None else None
+    bound = wmax is not None and nsq is not None
+    if bound:
+        _lib.check(L.hecka_wbound_f32(_p(A), _p(nsq), _p(gamma), Ma, Mb, B, _p(wmax), st), 'wbound')
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W),
-                                   _p(wmax) if wmax is not None else None, st), 'combine')
+                                   _p(wmax) if wmax is not None and not bound else None, st), 'combine')
+    gate = _GemmChain.enter(X.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -89,6 +168,7 @@ def gram_backward(A, C, cvec, X, detach_diag, xmax=None):
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
+    _GemmChain.leave(X.device, gate)
     return dX
 
 
@@ -309,13 +389,13 @@ class DiversityLayer(torch.autograd.Function):
     backward (from dval [M,M] or the scalar's gradient): head_bwd -> combine -> dX = W X."""
 
     @staticmethod
-    def forward(ctx, X, spec, detach_diag, reduce, gspec):
+    def forward(ctx, X, spec, detach_diag, reduce, gspec, pre=None):
         _check_features(X)
         X = X.contiguous()
         L = _lib.lib()
         M = X.shape[0]
         if gspec is None or gspec.kind == GRAM_LINEAR:
-            C, cvec, xmax = centered_gram(X, True)
+            C, cvec, xmax = pre if pre is not None else centered_gram(X, True)   # pre: centered_gram_multi's output
             aux = (cvec, xmax)
         else:
             C, rmean, gdiag, hband = transformed_gram(X, gspec, True)
@@ -343,7 +423,7 @@ class DiversityLayer(torch.autograd.Function):
         X, C, S, nsq = ctx.saved_tensors[:4]
         aux = ctx.saved_tensors[4:]
         if dout is None:
-            return torch.zeros_like(X), None, None, None, None
+            return torch.zeros_like(X), None, None, None, None, None
         L = _lib.lib()
         M = X.shape[0]
         A = torch.empty((M, M), device=X.device, dtype=torch.float32)
@@ -352,14 +432,14 @@ class DiversityLayer(torch.autograd.Function):
         _lib.check(L.hecka_head_bwd_f32(_p(S), _p(nsq), M, M, 0, *ctx.spec.args(), up_mat, up_scalar, ctx.scale, _p(A),
                                         _stream()), 'head_bwd')
         if len(aux) == 2:
-            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag, aux[1])
+            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag, aux[1], nsq)
         else:
             dX = transformed_gram_backward(A, C, aux[0], aux[1], aux[2], X, ctx.gspec)
-        return dX, None, None, None, None
+        return dX, None, None, None, None, None
 
 
-def diversity_layer(X, spec, detach_diag=True, reduce=None, gspec=None):
-    return DiversityLayer.apply(_features_f32(X), spec, detach_diag, reduce, gspec)
+def diversity_layer(X, spec, detach_diag=True, reduce=None, gspec=None, pre=None):
+    return DiversityLayer.apply(_features_f32(X), spec, detach_diag, reduce, gspec, pre)
 
 
 _OFFDIAG_INDEX = {}

@@ -62,6 +62,15 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* x
 int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P,
                           float* C, float* cvec, void* stream);
 
+/* hecka_gram_center_f32 for L tracked layers (same M and B, their own P) in ONE launch: X / sbar / xmax / C / cvec are
+ * HOST arrays of L device pointers (xmax, or any xmax[i], may be NULL), P a host array of L feature widths, layers
+ * ordered deepest (largest P) first.  Split-precision path only: B % 128 == 0, every P % 16 == 0, L <= 16; callers
+ * fall back to per-layer hecka_gram_center_f32 otherwise.  Replaces the Python loop over layers of
+ * ModelLayersKernel.forward (hyper/diversity/model_kernels.py:446-478) for the Gram stage: one layer alone leaves
+ * the second scheduling round of the GPU three-quarters empty (M*10 workgroups on 512 slots at B = 512). */
+int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
+                                int B, const int* P, float* const* C, float* const* cvec, void* stream);
+
 /* Pairwise inner products of vectorised Grams: S[i,j] = <Ca[i,:], Cb[j,:]>, Ca [Ma,K], Cb [Mb,K],
  * K = B*B.  Split-K over workgroups with a fixed-order (deterministic) second-stage sum.
  * Replaces vectorize_grams + the matmul of unit_vector_rows outputs (the norms are the diagonal
@@ -107,6 +116,13 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
  * wmax (may be NULL): [Ma] side output max |W_i| for the f16x3 dX GEMM (zeroed and filled by this call). */
 int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B,
                       int detach_diag, float* W, float* wmax, void* stream);
+
+/* Upper bound of max |W_i| from what already exists: wbound[i] = 2 sum_j |A[i,j]| sqrt(nsq[j]) + 2 max_b |gamma[i,b]|
+ * (nsq[j] = ||C_j||_F^2, the diagonal of hecka_pairwise_f32's S).  Accepted by hecka_gram_bwd_f32 in place of the exact
+ * maximum (a looser power-of-two scale only lowers the fp16 low plane's subnormal floor), so callers that have nsq pass
+ * wmax = NULL to hecka_combine_f32 and skip its pass over W.  No counterpart in the reference. */
+int hecka_wbound_f32(const float* A, const float* nsq, const float* gamma, int Ma, int Mb, int B, float* wbound,
+                     void* stream);
 
 /* out = A V   (A [Ma,Mb], V [Mb,K], out [Ma,K]) — backward of the generic pairwise inner product
  * (autograd of the matmul in hyper/diversity/__init__.py:47,108 for Grams that did not come from
@@ -174,7 +190,7 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
 
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
- * hecka_colmean_f32; both given enables f16x3 (see HECKA_GEMM_AUTO). */
+ * hecka_colmean_f32, or upper bounds of them (hecka_wbound_f32); both given enables f16x3 (see HECKA_GEMM_AUTO). */
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,
                        float* dX, void* stream);
 

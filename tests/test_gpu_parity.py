@@ -475,3 +475,37 @@ def test_resnet_train_step_matches_reference_golden():
     for k in z.files:
         if k.startswith('after:'):
             assert _relerr(after[k[6:]].cpu().numpy(), z[k]) <= 2e-5 or np.abs(z[k]).max() == 0, k
+
+
+@pytest.mark.parametrize('M,B,dims', [(8, 128, (64, 272, 32)), (5, 256, (48, 16))])
+def test_all_layers_gram_launch_matches_per_layer_and_oracle(M, B, dims, monkeypatch):
+    """hecka_gram_center_multi_f32 (every layer's centred Gram in one launch, deepest first) through
+    ModelLayersKernel: identical track['gram'] / loss / dX to the per-layer launches, and to the oracle at RTOL."""
+    from collections import OrderedDict
+    from oracle import hecka_ref as R
+    from hyper_amd import ops
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    dev = _dev()
+    cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'linear', 'start_weight': 1.0, 'weight_increase': 0.5},
+           'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031,
+                                feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
+    torch.manual_seed(M + B)
+    base = [torch.relu(torch.randn(M, B, p) + 0.2) for p in dims]
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HECKA_MULTI_GRAM', mode)
+        xs = [b.to(dev).requires_grad_(True) for b in base]
+        assert ops.multi_gram_eligible([x.detach() for x in xs])
+        track = OrderedDict()
+        out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
+        out.backward()
+        res[mode] = (out.item(), [x.grad.cpu() for x in xs], [t['gram'].cpu() for t in track['layer_track']])
+    assert res['1'][0] == res['0'][0]
+    for a, b in zip(res['1'][1] + res['1'][2], res['0'][1] + res['0'][2]):
+        assert torch.equal(a, b)
+    xo = [b.double().requires_grad_(True) for b in base]
+    ref = R.run_config(cfg, xo)
+    ref.backward()
+    assert abs(res['1'][0] - ref.item()) <= RTOL * abs(ref.item())
+    for g, o in zip(res['1'][1], xo):
+        assert _relerr(g.numpy(), o.grad.numpy()) <= RTOL
