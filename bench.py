@@ -68,6 +68,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: libraries that print banners there (RCCL prints its version block at
+    # communicator creation) get stderr instead; the real stdout comes back for the result line
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -141,6 +147,13 @@ def main():
             peak, hw = PEAK_BF16_MATRIX_TFLOPS / 6.0, {'hw_bf16_tflops': ach * 6.0, 'hw_bf16_peak': PEAK_BF16_MATRIX_TFLOPS}
         else:
             kname, peak, hw = 'gram_bwd_kernel (dX = W X, fp32 MFMA)', PEAK_F32_MATRIX_TFLOPS, {}
+        # HBM bytes per launch of the dominant kernel: not measurable from inside a run - taken from the committed
+        # rocprofv3 PMC passes of this same command (profiles/r01_hbm_traffic.json says how), single-GPU f16x3 only
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+        if world == 1 and mode == 0 and os.path.exists(tfile):
+            with open(tfile) as fh:
+                traffic = json.load(fh)['kernels']['gram_bwd_x6_kernel<1>']['hbm_bytes']
         flops_eval = sum(4.0 * M * B * B * p + 4.0 * M * M * B * B for p in DIMS)
         out = {
             'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
@@ -151,11 +164,14 @@ def main():
                                    'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
                        'loss': float(loss.item()), 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},
             'roofline': dict({'bound': 'mfma', 'kernel': kname, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                              'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': None}, **hw),
+                              'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': traffic}, **hw),
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -31,9 +31,13 @@ class _ShardedLayers(torch.autograd.Function):
         Ml = feats[0].shape[0]
         M, r0 = Ml * world, rank * Ml
         grams, works = [], []
-        for X in feats:                                   # local Grams; exchanges run behind them
-            X = X.contiguous()
-            C, cvec, xmax = backend.centered_gram(X, True)   # xmax: local members' max |X| (dX GEMM scaling)
+        feats = [X.contiguous() for X in feats]
+        # every layer's local Gram in one launch when the backend can (a rank's M/G members leave a per-layer launch
+        # far below one workgroup per GPU slot); otherwise layer by layer, the exchanges running behind them
+        multi = getattr(backend, 'multi_gram_eligible', None)
+        pre = backend.centered_gram_multi(feats) if multi is not None and multi(feats) else None
+        for li, X in enumerate(feats):
+            C, cvec, xmax = pre[li] if pre is not None else backend.centered_gram(X, True)   # xmax: max |X| (dX scaling)
             C_all = torch.empty((M,) + tuple(C.shape[1:]), device=C.device, dtype=C.dtype)
             cv_all = torch.empty((M, cvec.shape[1]), device=C.device, dtype=C.dtype)
             works.append((dist.all_gather_into_tensor(C_all, C, group=group, async_op=True),
