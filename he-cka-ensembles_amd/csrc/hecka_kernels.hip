@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
 // Fixed-order second stage: block = 16 outputs x 16 z-lanes; lane zl sums z = zl, zl+16, ... and the 16
 // lane sums are added in lane order (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int n,
-                                                            float* __restrict__ S) {
+                                                            float* __restrict__ S, float alpha) {
   __shared__ float red[16][17];
   const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + o;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     float tot = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) tot += red[r][o];
-    S[i] = tot;
+    S[i] = alpha * tot;
   }
 }
 
@@ -929,6 +929,26 @@ __global__ __launch_bounds__(kThreads, 2) void bgemm_kernel(GemmOperands g, floa
   });
 }
 
+// split-K form for small outputs over a long K (conv wgrad: [O, C kh kw] summed over N Ho Wo patches): slab z holds the
+// partial product over k in [z kchunk, (z+1) kchunk); splitk_reduce_kernel sums the slabs in a fixed order.
+template <int T, bool NN, bool VEC>
+__global__ __launch_bounds__(kThreads, 2) void bgemm_splitk_kernel(GemmOperands g, float* __restrict__ part, int tilesN,
+                                                                   int batch) {
+  using Tile = GemmTile<T, T, NN, VEC, NoPrologue>;
+  __shared__ typename Tile::Smem sm;
+  const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN, b = blockIdx.y, z = blockIdx.z;
+  const int kbeg = z * g.kchunk, kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
+  NoPrologue pro;
+  Tile tile;
+  tile.run(sm, g, g.A + (size_t)b * g.strideA, g.B + (size_t)b * g.strideB, ti * T, tj * T, kbeg, kend, pro);
+  float* out = part + ((size_t)z * batch + b) * g.rowsA * g.colsB;
+  const bool any = kend > kbeg;
+  tile.for_each([&](int lr, int lc, float v) {
+    const int row = ti * T + lr, col = tj * T + lc;
+    if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = any ? v : 0.f;
+  });
+}
+
 // ------------------------------------------------------------------------------------------
 // (11) batched-weight Conv2d as grouped GEMMs: patch gather / scatter around hecka_bgemm_f32.
 //      cols[m] is [R, Q]: R = C*kh*kw (+1 row of ones that carries the bias through the GEMM), Q = N*Ho*Wo.
@@ -1231,7 +1251,7 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   int rc = check_launch("pairwise");
   if (rc) return rc;
   const int n = Ma * Mb;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, nsplit, n, S);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, nsplit, n, S, 1.0f);
   return check_launch("pairwise_reduce");
 }
 
@@ -1432,6 +1452,54 @@ int hecka_bgemm_f32(const float* A, const float* Bm, float* C, int batch, int ro
   }
 #undef HECKA_BGEMM
   return check_launch("bgemm");
+}
+
+static int bgemm_nsplit(int batch, int rows, int cols, int K) {
+  const long long tiles = (long long)((rows + 63) / 64) * ((cols + 63) / 64) * batch;
+  if (rows >= 256 && cols >= 256) return 0;
+  if (tiles >= 256 || K < 4096) return 0;
+  long long want = (512 + tiles - 1) / tiles, maxs = K / 1024;
+  if (want > maxs) want = maxs;
+  return want >= 2 ? (int)want : 0;
+}
+
+size_t hecka_bgemm_splitk_workspace_bytes(int batch, int rows, int cols, int K) {
+  if (batch <= 0 || rows <= 0 || cols <= 0 || K <= 0) return 0;
+  return (size_t)bgemm_nsplit(batch, rows, cols, K) * batch * rows * cols * sizeof(float);
+}
+
+int hecka_bgemm_splitk_f32(const float* A, const float* Bm, float* C, int batch, int rows, int cols, int K,
+                           long long strideA, long long strideB, int nn, float alpha, void* ws, size_t ws_bytes,
+                           void* stream) {
+  clear_error();
+  if (!A || !Bm || !C || !ws) return fail(HECKA_EINVAL, "bgemm_splitk: null pointer%s");
+  if (batch <= 0 || rows <= 0 || cols <= 0 || K <= 0 || batch > 65535) return fail(HECKA_EINVAL, "bgemm_splitk: bad size%s");
+  const int nsplit = bgemm_nsplit(batch, rows, cols, K);
+  if (nsplit < 2) return fail(HECKA_EINVAL, "bgemm_splitk: this shape does not split (workspace query returns 0): use hecka_bgemm_f32%s");
+  const long long n = (long long)batch * rows * cols;
+  if (ws_bytes < (size_t)nsplit * n * sizeof(float) || n > 0x7fffffffLL)
+    return fail(HECKA_EWORKSPACE, "bgemm_splitk: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  GemmOperands g;
+  g.A = A; g.B = Bm;
+  g.strideA = strideA; g.strideB = strideB;
+  g.lda = K; g.ldb = nn ? cols : K;
+  g.rowsA = rows; g.colsB = cols;
+  g.K = K;
+  const int ktiles = (K + kBK - 1) / kBK;
+  g.kchunk = ((ktiles + nsplit - 1) / nsplit) * kBK;
+  const bool vec = (K % 4 == 0) && (!nn || cols % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) && aligned16(A) &&
+                   aligned16(Bm);
+  const int tilesM = (rows + 63) / 64, tilesN = (cols + 63) / 64;
+  dim3 grid(tilesM * tilesN, batch, nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)ws;
+#define HECKA_BGEMMS(NNF, V) \
+  hipLaunchKernelGGL((bgemm_splitk_kernel<64, NNF, V>), grid, dim3(kThreads), 0, st, g, part, tilesN, batch)
+  if (nn) { if (vec) HECKA_BGEMMS(true, true); else HECKA_BGEMMS(true, false); }
+  else    { if (vec) HECKA_BGEMMS(false, true); else HECKA_BGEMMS(false, false); }
+#undef HECKA_BGEMMS
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nsplit, (int)n, C, alpha);
+  return check_launch("bgemm_splitk");
 }
 
 static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,

@@ -32,6 +32,8 @@ SIGNATURES = {
     'hecka_gram_transform_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_transform_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'hecka_bgemm_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, ctypes.c_float, _vp]),
+    'hecka_bgemm_splitk_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i, _i]),
+    'hecka_bgemm_splitk_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, ctypes.c_size_t, _vp]),
     'hecka_im2col_f32': (_i, [_vp] + [_i] * 14 + [_vp, _vp]),
     'hecka_col2im_f32': (_i, [_vp] + [_i] * 14 + [_vp, _vp]),
     'hecka_gram_center_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),

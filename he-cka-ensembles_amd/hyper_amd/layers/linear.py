@@ -14,6 +14,14 @@ from .module import ParametersGroup, register_gen_module
 
 def _bgemm(A, B, batch, rows, cols, K, sA, sB, nn, alpha, bias=None, beta=0.0):
     out = torch.empty((batch, rows, cols), device=A.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.hecka_bgemm_splitk_workspace_bytes(batch, rows, cols, K) if bias is None else 0
+    if nbytes:     # small output over a long K (weight gradients): split-K slabs, fixed-order sum
+        ws = torch.empty((nbytes // 4,), device=A.device, dtype=torch.float32)
+        _lib.check(L.hecka_bgemm_splitk_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), batch, rows, cols, K, sA, sB,
+                                            int(nn), float(alpha), ws.data_ptr(), nbytes,
+                                            torch.cuda.current_stream().cuda_stream), 'bgemm_splitk')
+        return out
     _lib.check(_lib.lib().hecka_bgemm_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), batch, rows, cols, K, sA, sB,
                                           int(nn), float(alpha), bias.data_ptr() if bias is not None else None,
                                           float(beta), torch.cuda.current_stream().cuda_stream), 'bgemm')

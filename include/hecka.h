@@ -164,6 +164,14 @@ int hecka_bgemm_f32(const float* A, const float* B, float* C, int batch, int row
                     long long strideA, long long strideB, int nn, float alpha, const float* bias, float beta,
                     void* stream);
 
+/* Split-K form of hecka_bgemm_f32 (no bias) for a small output over a long K - the weight gradient of a convolution is
+ * [O, C kh kw] summed over all N Ho Wo patches.  hecka_bgemm_splitk_workspace_bytes returns 0 when the shape should
+ * not be split (then call hecka_bgemm_f32); otherwise `ws` takes the partial slabs, summed in a fixed order. */
+size_t hecka_bgemm_splitk_workspace_bytes(int batch, int rows, int cols, int K);
+int hecka_bgemm_splitk_f32(const float* A, const float* B, float* C, int batch, int rows, int cols, int K,
+                           long long strideA, long long strideB, int nn, float alpha, void* ws, size_t ws_bytes,
+                           void* stream);
+
 /* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
  * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
  * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an

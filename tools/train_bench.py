@@ -1,0 +1,114 @@
+"""Train steps/s of the reference's model configurations (BASELINE.json configs[0..2]) on synthetic data of the dataset's
+shape: FixedEnsembleModel forward -> RepulsiveKernel (cross-entropy + HE-CKA feature repulsion) -> backward -> optimizer.
+
+    python tools/train_bench.py mnist|toy|cifar [--impl amd|ref] [--steps K] [--members M] [--batch B]
+
+--impl amd : hyper_amd on cuda:0 (HIP kernels).
+--impl ref : the real reference on this machine's CPU cores (build container only: needs /root/reference; shims as in
+             tests/golden/make_golden.py).  A reported baseline, never part of the product path.
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd')]
+import torch  # noqa: E402
+
+
+def fk(kernel, **params):
+    d = {'name': 'feature', 'detach_diag': True, 'kernel': kernel}
+    if params:
+        d['params'] = params
+    return d
+
+
+def configs(members):
+    mnist_w = {'name': 'start_end_linear', 'first_layer': 0.387, 'middle_start': 0.746, 'middle_increase': 1.267, 'last_layer': 3.63}
+    return {
+        # configs/mnist/base.yml + ens/he-lin.yml
+        'mnist': dict(members=members or 5, batch=300, x=(1, 28, 28), classes=10, opt='adamw',
+                      hyper={'name': 'ensemble', 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
+                      method={'name': 'repulsive_kernel', 'gamma': 10.5, 'warmup': 600, 'ind_loss': {'name': 'cross_entropy'},
+                              'model_kernel': {'name': 'model_layers', 'layer_weighting': mnist_w,
+                                               'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031, 'feature_kernel': fk('linear')}}}),
+        # configs/toy/fourclass/base.yml + ens/he-rbf.yml
+        'toy': dict(members=members or 30, batch=100, x=(2,), classes=4, opt='adamw',
+                    hyper={'name': 'ensemble', 'target': {'name': 'mlp', 'activation': 'crater', 'layers': [
+                        {'in': 2, 'out': 30}, {'in': 30, 'out': 40}, {'in': 40, 'out': 30}, {'in': 30, 'out': 4}]}},
+                    method={'name': 'repulsive_kernel', 'gamma': 7.5, 'warmup': 0.0035, 'beta_ind': 2.25, 'ind_loss': {'name': 'cross_entropy'},
+                            'model_kernel': {'name': 'model_layers', 'layer_weighting': {'name': 'list', 'weights': [0.05, 0.35, 1.0, 0.85]},
+                                             'layer_kernel': {'name': 'he', 'he_s': 5.0, 'eps': 0.000005, 'arc_eps': 0.00305,
+                                                              'feature_kernel': fk('rbf', param=5.025)}}}),
+        # configs/cifar10/base.yml + ens/he-lin.yml (BASELINE.json quotes 10 members)
+        'cifar': dict(members=members or 10, batch=128, x=(3, 32, 32), classes=10, opt='sgd',
+                      hyper={'name': 'ensemble', 'target': {'name': 'resnet18', 'num_classes': 10, 'act': 'relu'}},
+                      method={'name': 'repulsive_kernel', 'gamma': 1.0, 'beta_ind': 5.0, 'warmup': 10, 'ind_loss': {'name': 'cross_entropy'},
+                              'model_kernel': {'name': 'model_layers',
+                                               'layer_weighting': {'name': 'list', 'weights': [0.0, 0.15, 0.25, 0.35, 0.4, 0.45, 0.5, 0.0001], 'normalize': False},
+                                               'layer_kernel': {'name': 'he', 'eps': 0.001, 'arc_eps': 0.001, 'use_exp': True, 'feature_kernel': fk('linear')}}}),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config', choices=['mnist', 'toy', 'cifar'])
+    ap.add_argument('--impl', default='amd', choices=['amd', 'ref'])
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--members', type=int, default=0)
+    ap.add_argument('--batch', type=int, default=0)
+    args = ap.parse_args()
+    c = configs(args.members)[args.config]
+    M, B = c['members'], args.batch or c['batch']
+    c['hyper']['ensemble_size'] = M
+    c['method']['num'] = M
+    if args.impl == 'ref':
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+        import make_golden
+        make_golden._import_reference()
+        import hyper.target.lenet, hyper.target.mlp, hyper.target.resnet  # noqa: F401,E401
+        import hyper.generators.ensemble  # noqa: F401
+        from hyper.generators.base import build_generator
+        from hyper.diversity.methods import build_method
+        dev = torch.device('cpu')
+    else:
+        import hyper_amd.target  # noqa: F401
+        from hyper_amd.generators import build_generator
+        from hyper_amd.diversity.methods import build_method
+        dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    hyper = build_generator(c['hyper']).to(dev)
+    method = build_method(c['method']).to(dev)
+    params = list(hyper.parameters()) + list(method.parameters())
+    opt = (torch.optim.AdamW(params, lr=1e-3) if c['opt'] == 'adamw' else torch.optim.SGD(params, lr=0.01, momentum=0.9))
+    X = torch.randn(B, *c['x'], device=dev)
+    Y = torch.randint(0, c['classes'], (B,), device=dev)
+    trainer = types.SimpleNamespace(training=True)
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        track = hyper(params=list(range(M)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+        track = method(trainer, track['params'], [], track, X, Y, step=1000 + i)
+        track['loss'].backward()
+        opt.step()
+        return track['loss']
+
+    sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
+    for i in range(args.warmup):
+        loss = step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    print('%s impl=%s M=%d B=%d: %.2f ms/step  %.1f steps/s  loss %.4f%s' % (
+        args.config, args.impl, M, B, dt * 1e3, 1.0 / dt, float(loss),
+        '  (%d CPU threads)' % torch.get_num_threads() if args.impl == 'ref' else ''))
+
+
+if __name__ == '__main__':
+    main()
