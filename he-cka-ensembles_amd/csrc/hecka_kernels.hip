@@ -958,25 +958,34 @@ struct ConvGeom {
   int N, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo;
 };
 
+// V = 4: a thread writes four consecutive output positions of one patch row (Wo % 4 == 0: same image row) as one
+// 16-byte store - a quarter of the index arithmetic per element
+template <int V>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, ConvGeom g, int ones_row,
                                                      float* __restrict__ cols) {
   const long long Q = (long long)g.N * g.Ho * g.Wo;
-  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long q = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (q >= Q) return;
   const int r = blockIdx.y, m = blockIdx.z;
   const int K = g.C * g.kh * g.kw, R = K + (ones_row ? 1 : 0);
-  float v;
+  float v[V];
   if (r == K) {
-    v = 1.0f;
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 1.0f;
   } else {
     const int j = r % g.kw, i = (r / g.kw) % g.kh, c = r / (g.kw * g.kh);
     const int ow = (int)(q % g.Wo), oh = (int)((q / g.Wo) % g.Ho), n = (int)(q / ((long long)g.Wo * g.Ho));
-    const int h = oh * g.sh - g.ph + i * g.dh, w = ow * g.sw - g.pw + j * g.dw;
-    v = (h >= 0 && h < g.H && w >= 0 && w < g.W)
-            ? x[((((size_t)m * g.N + n) * g.C + c) * g.H + h) * g.W + w]
-            : 0.0f;
+    const int h = oh * g.sh - g.ph + i * g.dh;
+    const float* row = x + ((((size_t)m * g.N + n) * g.C + c) * g.H + (h >= 0 && h < g.H ? h : 0)) * g.W;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int w = (ow + e) * g.sw - g.pw + j * g.dw;
+      v[e] = (h >= 0 && h < g.H && w >= 0 && w < g.W) ? row[w] : 0.0f;
+    }
   }
-  cols[((size_t)m * R + r) * Q + q] = v;
+  float* out = cols + ((size_t)m * R + r) * Q + q;
+  if (V == 4) *reinterpret_cast<f32x4*>(out) = f32x4{v[0], v[1], v[2], v[3]};
+  else out[0] = v[0];
 }
 
 // dx[m,n,c,h,w] = sum over the patches that read this pixel (a gather: deterministic, no atomics)
@@ -1523,8 +1532,12 @@ int hecka_im2col_f32(const float* x, int Mx, int N, int C, int H, int W, int kh,
   const long long Q = (long long)N * g.Ho * g.Wo;
   const int R = C * kh * kw + (ones_row ? 1 : 0);
   if (Mx <= 0 || Mx > 65535 || R > 65535 || Q > (1ll << 38)) return fail(HECKA_EINVAL, "im2col: size out of range%s");
-  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Q + 255) / 256), R, Mx), dim3(256), 0, (hipStream_t)stream, x, g,
-                     ones_row, cols);
+  if (g.Wo % 4 == 0 && aligned16(cols))
+    hipLaunchKernelGGL(im2col_kernel<4>, dim3((unsigned)((Q / 4 + 255) / 256), R, Mx), dim3(256), 0, (hipStream_t)stream, x,
+                       g, ones_row, cols);
+  else
+    hipLaunchKernelGGL(im2col_kernel<1>, dim3((unsigned)((Q + 255) / 256), R, Mx), dim3(256), 0, (hipStream_t)stream, x, g,
+                       ones_row, cols);
   return check_launch("im2col");
 }
 

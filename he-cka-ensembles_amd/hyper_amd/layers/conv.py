@@ -3,8 +3,10 @@ The reference loops F.conv2d over the ensemble members and stacks the results; h
 grouped GEMM on fp32 MFMA: patches are gathered once (libhecka hecka_im2col_f32, shared across members when the
 input is a plain image batch), forward / wgrad / dgrad are hecka_bgemm_f32 calls with the parameter scaling in the
 epilogue and the bias carried as an extra weight column against a row of ones, and hecka_col2im_f32 gathers the
-input gradient.  Patches are re-gathered in backward instead of being kept (R*Q floats per member)."""
+input gradient.  The gathered patches are kept for the weight gradient (HECKA_CONV_KEEP_COLS_GB per layer, default 8)
+and re-gathered in backward beyond that."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -68,20 +70,24 @@ class BatchedConv2d(torch.autograd.Function):
         Wf = Wf.contiguous()
         R = Wf.shape[2]
         y = _bgemm(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale)      # [M,O,Q]
-        ctx.save_for_backward(x5, W)
+        # the gathered patches are kept for the weight gradient while they are small next to 288 GB of HBM (23 GB for
+        # all of ResNet18 at M=10, N=128); larger ones are re-gathered in backward
+        keep = cols.numel() * 4 <= int(float(os.environ.get('HECKA_CONV_KEEP_COLS_GB', '8')) * 2 ** 30)
+        ctx.save_for_backward(x5, W, cols if keep else None)
         ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
         return y.view(M, O, N, Ho, Wo).transpose(1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        x5, W = ctx.saved_tensors
+        x5, W, cols = ctx.saved_tensors
         scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo) = ctx.cfg
         M, O, C, kh, kw = W.shape
         K, Q = C * kh * kw, N * Ho * Wo
         dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            cols = _im2col(x5, geom, has_bias)
+            if cols is None:
+                cols = _im2col(x5, geom, has_bias)
             R = cols.shape[1]
             dWf = _bgemm(dyq, cols, M, O, R, Q, O * Q, 0 if shared else R * Q, False, scale)   # dy cols^T  [M,O,R]
             dW = dWf[:, :, :K].reshape(W.shape)
