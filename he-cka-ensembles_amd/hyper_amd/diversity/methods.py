@@ -1,6 +1,6 @@
 """Training "methods" on the hot path (hyper/diversity/methods.py: registry :18-39, ParticleMethods `mle`
-:42-164, RepulsiveKernel `repulsive_kernel` :309-360).  `svgd` / `function_svgd` are out of scope
-(SURVEY.md 8f #2)."""
+:42-164, SVGD `svgd` :167-226 with feature-space (`model_layers`) kernels, RepulsiveKernel `repulsive_kernel`
+:309-360).  Weight-space SVGD (`weight` kernels) and `function_svgd` are not built."""
 import copy
 import traceback
 from collections import OrderedDict
@@ -91,6 +91,48 @@ class ParticleMethods(nn.Module):
             if key in config:
                 config[key] = build_loss(config[key])
         return config
+
+
+def filter_params(param_dict):
+    """Flattened parameter dict without BatchNorm buffers (WeightKernel.filter_params, model_kernels.py:166-173)."""
+    return OrderedDict((k, v) for k, v in flatten_keys(param_dict).items() if '.norm_buffer.' not in k)
+
+
+@register_method('svgd')
+class SVGD(ParticleMethods):
+    """Stein variational gradient descent on the particles with a FEATURE-space kernel: the [M,M] matrix of a
+    `model_layers` kernel with `reduction: none` (configs/*/svgd/{cka,he}-*.yml).  Per flat parameter block p:
+        grad_p = (K @ d(-loss)/dp - dK.sum()/dp) / num         (kde: d(-loss)/dp - (dK.sum()/dp) / K.sum(1))
+    and -grad_p is pushed back through the generator.  The kernel matrix and its gradient come from the HIP path
+    (ops.diversity_layer with reduce=None: head_bwd takes the all-ones upstream matrix)."""
+
+    def __init__(self, num, model_kernel, ind_loss, kde=False, beta_ind=1.0):
+        super().__init__(num, model_kernel, ind_loss, beta_ind=beta_ind)
+        if isinstance(model_kernel, WeightKernelUnsupported):
+            raise NotImplementedError('hyper_amd svgd: weight-space kernels are not built (feature-space kernels only)')
+        self.weight_space = False
+        self.kde = kde
+
+    @staticmethod
+    def grads(var, grad_var, retain_graph=True, create_graph=False, **kwargs):
+        return torch.autograd.grad(var.sum(), grad_var, retain_graph=retain_graph, create_graph=create_graph, **kwargs)
+
+    def backward(self, trainer, params, shared_params, track, x, gt, retain_graph=False, create_graph=False, inputs=None):
+        flat_params = filter_params(params)
+        all_flat = list(flat_params.values()) + list(shared_params)
+        loss = self.beta_ind * track['ind_loss']
+        drive = self.grads(-loss, all_flat, retain_graph=True, create_graph=create_graph, allow_unused=True)
+        kern = self.model_kernel(flat_params, track['feats_ind'], track['pred_ind'], track)
+        kgrads = self.grads(kern, all_flat, retain_graph=True, create_graph=create_graph, allow_unused=True)
+        for p, gd, gk in zip(all_flat, drive, kgrads):
+            if gd is None:
+                continue
+            if self.kde:
+                grad = gd - gk / kern.sum(1, keepdim=True)
+            else:
+                grad = (torch.matmul(kern, gd) - gk) / self.num
+            p.backward(inputs=inputs, gradient=-grad, retain_graph=True, create_graph=create_graph)
+        return loss, {}
 
 
 @register_method('repulsive_kernel')

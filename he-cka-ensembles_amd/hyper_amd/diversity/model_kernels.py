@@ -144,8 +144,9 @@ class _PairwiseHead(BaseModelKernel):
     def _values(self, feats, track, reduce=None, pre=None):
         """Fast path only: value matrix [M,M] (reduce=None) or the reduced scalar."""
         fk = self.feature_kernel
-        out, gram = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce, fk.gram_spec(), pre)
+        out, gram, S, nsq = ops.diversity_layer(fk.flatten(feats), self._spec(), fk.detach_diag, reduce, fk.gram_spec(), pre)
         track['gram'] = gram
+        track['gram_inner'] = (S, nsq)   # <C_i, C_j> and ||C_i||^2: lets the `ckas` metric skip its own pass over the Grams
         return out
 
     def shares_gram_launch(self):

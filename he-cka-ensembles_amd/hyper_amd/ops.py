@@ -414,12 +414,12 @@ class DiversityLayer(torch.autograd.Function):
             _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), None, _p(out), ctx.scale, st), 'head_fwd')
         ctx.save_for_backward(X, C, S, nsq, *aux)
         ctx.spec, ctx.detach_diag, ctx.reduced, ctx.gspec = spec, bool(detach_diag), reduce is not None, gspec
-        ctx.mark_non_differentiable(C)
-        ctx.set_materialize_grads(False)   # no zeros_like(C) for the non-differentiable by-product
-        return out, C
+        ctx.mark_non_differentiable(C, S, nsq)
+        ctx.set_materialize_grads(False)   # no zeros_like(C) for the non-differentiable by-products
+        return out, C, S, nsq              # S [M,M] / nsq [M]: inner products and squared norms of the Grams (metrics)
 
     @staticmethod
-    def backward(ctx, dout, _dC):
+    def backward(ctx, dout, _dC, _dS=None, _dn=None):
         X, C, S, nsq = ctx.saved_tensors[:4]
         aux = ctx.saved_tensors[4:]
         if dout is None:

@@ -256,6 +256,45 @@ def run_resnet_step(dtype, tag):
           list(track['feats_ind'].keys()))
 
 
+SVGD_CFG = {
+    'hyper': {'name': 'ensemble', 'ensemble_size': 5, 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
+    'method': {'name': 'svgd', 'num': 5, 'ind_loss': {'name': 'cross_entropy'},
+               'model_kernel': {'name': 'model_layers', 'reduction': 'none',
+                                'layer_kernel': cka('cossim', eps=0.00025, detach_right=True, reduction='none'),
+                                'layer_weighting': {'name': 'start_end_linear', 'first_layer': 0.0, 'middle_start': 0.5,
+                                                    'middle_increase': 1.75, 'last_layer': 6.5}}},
+}
+
+
+def run_svgd_step(dtype, tag):
+    """One SVGD update of configs/mnist/svgd/cka-cossim.yml (feature-space CKA kernel matrix, reduction none,
+    detach_right) with the REAL reference: method.forward, method.backward -> gradients on the ensemble parameters."""
+    import hyper.target.lenet  # noqa: F401
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    rk.KERN_PARAMS['cossim'] = {'eps': 1e-6}
+    torch.manual_seed(52)
+    hyper = build_generator(SVGD_CFG['hyper']).to(dtype)
+    method = build_method(SVGD_CFG['method']).to(dtype)
+    gen = torch.Generator().manual_seed(9)
+    X = torch.randn(12, 1, 28, 28, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 10, (12,), generator=gen)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    rec = {'config': json.dumps(SVGD_CFG), 'X': X.numpy(), 'Y': Y.numpy(), 'loss': loss.detach().numpy(),
+           'pred': track['pred'].detach().numpy()}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'svgd_step_%s.npz' % tag), **rec)
+    print('svgd_step', tag, 'loss', float(loss))
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -291,6 +330,7 @@ def main():
         run_train_step(dtype, tag)
         run_lenet_step(dtype, tag)
     run_resnet_step(torch.float64, 'f64')
+    run_svgd_step(torch.float64, 'f64')
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)

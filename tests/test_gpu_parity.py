@@ -509,3 +509,56 @@ def test_all_layers_gram_launch_matches_per_layer_and_oracle(M, B, dims, monkeyp
     assert abs(res['1'][0] - ref.item()) <= RTOL * abs(ref.item())
     for g, o in zip(res['1'][1], xo):
         assert _relerr(g.numpy(), o.grad.numpy()) <= RTOL
+
+
+def test_svgd_step_matches_reference_golden():
+    """configs/mnist/svgd/cka-cossim.yml: one SVGD update - feature-space CKA kernel MATRIX
+    (reduction none, detach_right, cossim Grams) and its gradient from the HIP path, K @ drive - dK - against the
+    update the REAL reference produced (tests/golden/svgd_step_f64.npz)."""
+    import json
+    import os
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'svgd_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+
+
+def test_ckas_metric_from_loss_byproducts_matches_oracle():
+    """`ckas` metric: mean pairwise CKA per layer from the inner products the loss already holds,
+    vs pairwise_cossim(track gram).mean() of the oracle (metrics.py:91)."""
+    from collections import OrderedDict
+    from oracle import hecka_ref as R
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from hyper_amd.experiments.metrics import build_metric
+    dev = _dev()
+    cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+           'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031,
+                                feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
+    torch.manual_seed(11)
+    xs = [torch.relu(torch.randn(6, 40, p)) for p in (24, 9, 130)]
+    track = {'ind_kernel': OrderedDict()}
+    build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x.to(dev)) for i, x in enumerate(xs)), None, track['ind_kernel'])
+    logged = build_metric({'name': 'ckas'}).log_train(None, 6, None, None, track)
+    assert list(logged) == ['cka_ind_%d/train' % (i + 1) for i in range(3)]
+    otrack = {}
+    R.run_config(cfg, [x.double() for x in xs], otrack)
+    for i, t in enumerate(otrack['layer_track']):
+        ref = R.pairwise_cossim(t['gram']).mean().item()
+        assert abs(logged['cka_ind_%d/train' % (i + 1)] - ref) <= RTOL * abs(ref)
