@@ -84,7 +84,9 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
 // 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
 // gathers 8 k of ONE column with dword loads (a wave-load = 256 contiguous bytes of one k-row).
 // Pro: transform of the staged fp32 values (centring), NT only.
-template <int TM, int TN, bool NN, class Pro, int SCHEME = 0>
+// FOLD = false: one accumulation chain over the whole K (no local chains, 64 fewer VGPRs: a third workgroup per CU);
+// only for short K - the 16-bit MFMA's truncation bias grows with the chain (about -5e-10 of sum|a.b| per k).
+template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true>
 struct GemmTileX6 {
   static constexpr int NP = SCHEME == 1 ? 2 : 3;
   static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
@@ -297,12 +299,16 @@ struct GemmTileX6 {
       for (int n = 0; n < 12; ++n) {
         const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
         {
-          f32x16 c = loc[i][j];
-          if (decltype(FIRST)::value && e == 0) {
+          if (FOLD) {
+            f32x16 c = loc[i][j];
+            if (decltype(FIRST)::value && e == 0) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) c[q] = 0.f;
+              for (int q = 0; q < 16; ++q) c[q] = 0.f;
+            }
+            loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], acc[i][j], 0, 0, 0);
           }
-          loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (n == 4) { if (load) gload_a(NSET, kt + 3); }
@@ -330,6 +336,7 @@ struct GemmTileX6 {
       __syncthreads();
     };
     auto fold = [&]() __attribute__((always_inline)) {
+      if (!FOLD) return;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll

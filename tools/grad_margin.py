@@ -1,0 +1,33 @@
+"""Gradient error of the full HE layer at bench member / sample counts vs the fp64 oracle (same GPU): how much of the
+1e-5 budget each GEMM variant uses.   python tools/grad_margin.py"""
+import os
+import sys
+from collections import OrderedDict
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd')]
+import torch  # noqa: E402
+from oracle import hecka_ref as R  # noqa: E402
+from hyper_amd.diversity.model_kernels import build_model_kernel  # noqa: E402
+
+dev = torch.device('cuda:0')
+M, B = 64, 512
+for P in (512, 2048):
+    for style in ('randn', 'correlated', 'relu'):
+        torch.manual_seed(1234)
+        X = torch.randn(M, B, P, device=dev)
+        if style == 'correlated':
+            X = 0.7 * torch.randn(1, B, P, device=dev) + 0.3 * X
+        if style == 'relu':
+            X = torch.relu(X + 0.5)
+        for lk in (dict(eps=0.0025, arc_eps=0.031), dict(eps=0.001, arc_eps=0.001, use_exp=True)):
+            cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+                   'layer_kernel': dict(name='he', feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}, **lk)}
+            x = X.clone().requires_grad_(True)
+            out = build_model_kernel(cfg).to(dev)(None, OrderedDict(a=x), None, OrderedDict())
+            out.backward()
+            xo = X.double().requires_grad_(True)
+            ref = R.run_config(cfg, [xo])
+            ref.backward()
+            err = float((x.grad.double() - xo.grad).abs().max() / xo.grad.abs().max())
+            print('P=%4d %-10s exp=%d  loss rel err %.2e   grad max-norm rel err %.2e' % (
+                P, style, int('use_exp' in lk), abs(out.item() - ref.item()) / abs(ref.item()), err))
