@@ -409,7 +409,7 @@ class DiversityLayer(torch.autograd.Function):
             ctx.scale = 1.0
         else:
             count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
-            ctx.scale = 1.0 / count
+            ctx.scale = 1.0 / count if count else float('nan')   # a single member has no pairs: mean of nothing = NaN
             out = torch.empty((), device=X.device, dtype=torch.float32)
             _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), None, _p(out), ctx.scale, st), 'head_fwd')
         ctx.save_for_backward(X, C, S, nsq, *aux)

@@ -562,3 +562,57 @@ def test_ckas_metric_from_loss_byproducts_matches_oracle():
     for i, t in enumerate(otrack['layer_track']):
         ref = R.pairwise_cossim(t['gram']).mean().item()
         assert abs(logged['cka_ind_%d/train' % (i + 1)] - ref) <= RTOL * abs(ref)
+
+
+@pytest.mark.parametrize('M,B,P', [(2, 2, 1), (2, 3, 5), (3, 1, 4), (1, 6, 3), (7, 129, 1)])
+def test_smallest_shapes_match_oracle(M, B, P):
+    """Edge sizes: two members, two samples, one feature, a single sample (every centred Gram is exactly zero: cos = 0/eps),
+    a single member (no pairs: the off-diagonal mean is NaN in the reference - 0/0 - and here)."""
+    from collections import OrderedDict
+    from oracle import hecka_ref as R
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    dev = _dev()
+    cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+           'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031,
+                                feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
+    torch.manual_seed(M * 100 + B * 10 + P)
+    x0 = torch.randn(M, B, P)
+    x = x0.to(dev).requires_grad_(True)
+    out = build_model_kernel(cfg).to(dev)(None, OrderedDict(a=x), None, OrderedDict())
+    xo = x0.double().requires_grad_(True)
+    ref = R.run_config(cfg, [xo])
+    if M == 1:
+        assert torch.isnan(ref) and torch.isnan(out)
+        return
+    out.backward()
+    ref.backward()
+    assert abs(out.item() - ref.item()) <= RTOL * max(abs(ref.item()), 1e-30)
+    scale = max(float(xo.grad.abs().max()), 1e-30)
+    assert float((x.grad.cpu().double() - xo.grad).abs().max()) <= RTOL * scale + 1e-12
+
+
+def test_cossim_zero_row_is_nan_and_the_method_masks_it():
+    """cossim_gram has no eps (kernels.py:145-169): a zero feature row gives NaN, as in the reference; RepulsiveKernel
+    then counts the repulsive term as 0 (methods.py:342)."""
+    import types
+    from collections import OrderedDict
+    from oracle import hecka_ref as R
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from hyper_amd.diversity.methods import build_method
+    dev = _dev()
+    mk = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+          'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031,
+                               feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'cossim'})}
+    torch.manual_seed(3)
+    x0 = torch.randn(4, 6, 5)
+    x0[1, 2] = 0.0
+    assert torch.isnan(R.run_config(mk, [x0.double()]))
+    out = build_model_kernel(mk).to(dev)(None, OrderedDict(a=x0.to(dev)), None, OrderedDict())
+    assert torch.isnan(out)
+    method = build_method({'name': 'repulsive_kernel', 'num': 4, 'gamma': 2.0, 'model_kernel': mk,
+                           'ind_loss': {'name': 'cross_entropy'}}).to(dev)
+    pred = torch.randn(4, 6, 3, device=dev)
+    track = {'pred_ind': pred, 'feats_ind': OrderedDict(a=x0.to(dev)), 'pred_ood': None, 'feats_ood': None}
+    track = method(types.SimpleNamespace(training=True), OrderedDict(), [], track, None, torch.randint(0, 3, (6,), device=dev), step=5)
+    assert torch.isnan(track['ind_rep_loss']) and torch.isfinite(track['loss'])
+    assert abs(track['loss'].item() - track['ind_loss'].item()) < 1e-6
