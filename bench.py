@@ -64,6 +64,10 @@ def cpu_baseline():
                       'untimed eval' % (n, torch.__version__, dt)}
 
 
+SHARD_NOTE = {'slice': 'all-to-all of Gram column slices (1/G of the exchange and of every stage per rank)',
+              'gather': 'all_gather of centred Grams'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,7 +106,7 @@ def main():
     kern = build_model_kernel(CFG).to(dev)
     if world > 1 or force_sharded:
         from hyper_amd.parallel import ShardedModelLayersKernel
-        kern = ShardedModelLayersKernel(kern)        # all_gather of centred Grams over RCCL, one scalar all_reduce
+        kern = ShardedModelLayersKernel(kern)        # all-to-all of Gram column slices over RCCL (hyper_amd/parallel.py)
     xs = [f.requires_grad_(True) for f in feats]
     fdict = OrderedDict((str(i), x) for i, x in enumerate(xs))
 
@@ -163,7 +167,7 @@ def main():
             'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'parallelism': 'members sharded %d-way, all_gather of centred Grams' % world if world > 1 else 'single GPU',
+            'config': {'parallelism': 'members sharded %d-way, %s' % (world, SHARD_NOTE[os.environ.get('HECKA_SHARD_MODE', 'slice')]) if world > 1 else 'single GPU',
                        'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
                                    'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
                        'loss': float(loss.item()), 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},

@@ -378,7 +378,8 @@ __global__ void coef_gamma_kernel(const float* __restrict__ A, const float* __re
 // MODE 1: symmetrised Gram gradient W (above)
 template <bool VEC, int MODE, bool FULL>
 __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, const float* __restrict__ gamma, int B,
-                                                              int detach_diag, float* __restrict__ W, int tilesN) {
+                                                              int detach_diag, float* __restrict__ W, int tilesN,
+                                                              long long n_start) {
   using Tile = GemmTile<64, 128, true, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(kThreads, 2) void combine_kernel(GemmOperands g, co
     if (i < g.rowsA && n < g.colsB) {
       float w = v;
       if (MODE == 1) {
-        const int a = n / B, b = n - a * B;
+        const long long ng = n_start + n;   // Gram element of this column (C may be a column slice of [Mb, B*B])
+        const int a = (int)(ng / B), b = (int)(ng - (long long)a * B);
         w = 2.f * v + gamma[(size_t)i * B + a] - gamma[(size_t)i * B + b];
         if (detach_diag && a == b) w = 0.f;
       }
@@ -419,7 +421,7 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {   // 256-thr
 template <int RB>
 __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __restrict__ A, const float* __restrict__ C,
                                                                 const float* __restrict__ gamma, int B, int detach_diag,
-                                                                float* __restrict__ W) {
+                                                                float* __restrict__ W, long long N, long long chunk0) {
   __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]
   __shared__ float sG[4][32 * RB];   // per wave: gamma[:, a] of the chunk's Gram row a
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, j = lane & 31;
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
     sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
   }
   __syncthreads();
-  const long long N = (long long)B * B;
+  // C and W hold N columns per row: the Gram elements [64 chunk0, 64 chunk0 + N) of the B*B (all of them when
+  // chunk0 = 0 and N = B*B; a column slice in the member-sharded path)
   const int strips = B / 64;
   const long long nchunks = N / 64;
   // buffer addressing: one per-lane byte offset per chunk + scalar row offsets (no 64-bit pointers kept per row)
@@ -436,14 +439,14 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(W, 0, (int)(32 * RB * N * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gamma), 0, 32 * RB * B * 4, 0x00020000);
   const unsigned rowN = (unsigned)N * 4u;
-  // chunk c -> Gram row a = c / strips, columns b0 = 64 (c % strips); the B fragments of the wave's NEXT chunk are
+  // chunk c (global chunk cg = chunk0 + c) -> Gram row a = cg / strips, columns b0 = 64 (cg % strips); the B fragments of the wave's NEXT chunk are
   // loaded while the 128 MFMAs of the current one issue (two register sets)
   const long long cstep = (long long)gridDim.x * 4;
   long long c = (long long)blockIdx.x * 4 + wave;
   f32x2 bf[2][32];
   auto load_b = [&](auto SET, long long cc) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const unsigned n0 = (unsigned)(cc / strips) * B + (unsigned)(cc % strips) * 64;
+    const unsigned n0 = (unsigned)cc * 64u;
     const unsigned vC = (unsigned)h * rowN + (n0 + 2 * j) * 4u;
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks)
@@ -451,8 +454,9 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   };
   auto chunk = [&](auto SET, long long cc) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const int a = (int)(cc / strips), b0 = (int)(cc % strips) * 64;
-    const unsigned n0 = (unsigned)a * B + b0;
+    const long long cg = chunk0 + cc;
+    const int a = (int)(cg / strips), b0 = (int)(cg % strips) * 64;
+    const unsigned n0 = (unsigned)cc * 64u;
     if (lane < 32 * RB) sG[wave][lane] = gamma[(size_t)lane * B + a];
     if (cc + cstep < nchunks) load_b(std::integral_constant<int, 1 - S>{}, cc + cstep);
     f32x16 acc[RB][2];
@@ -1274,7 +1278,7 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
 }
 
 static int combine_impl(const float* A, const float* C, const float* gamma, int Ma, int Mb, long long N, int B,
-                        int detach_diag, float* W, float* wmax, void* stream, int mode) {
+                        int detach_diag, float* W, float* wmax, void* stream, int mode, long long n_start = 0) {
   clear_error();
   if (!A || !C || !W || (mode == 1 && !gamma)) return fail(HECKA_EINVAL, "combine: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || N <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
@@ -1292,14 +1296,16 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   const bool full = vec && (Ma % 64 == 0) && (N % 128 == 0) && (Mb % kBK == 0);
   unsigned* wm = reinterpret_cast<unsigned*>(wmax);
   if (wm && hipMemsetAsync(wm, 0, (size_t)Ma * sizeof(unsigned), st) != hipSuccess) return check_launch("combine (memset)");
-  if (mode == 1 && Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && aligned16(A) && aligned16(C) && aligned16(gamma) &&
-      aligned16(W) && !getenv("HECKA_COMBINE_TILED")) {
+  if (mode == 1 && Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && N % 64 == 0 && n_start % 64 == 0 && aligned16(A) &&
+      aligned16(C) && aligned16(gamma) && aligned16(W) && !getenv("HECKA_COMBINE_TILED")) {
     const char* ge = getenv("HECKA_COMBINE_WGS");
-    const unsigned nwg = (unsigned)std::min<long long>(N / 256, ge ? atoi(ge) : 512);
+    const unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, ge ? atoi(ge) : 512));
     if (Ma == 64)
-      hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W);
+      hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+                         n_start / 64);
     else
-      hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W);
+      hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+                         n_start / 64);
     if (wm) {
       const int chunks = (int)(N >= (1 << 16) ? 16 : 1);
       hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, Ma), dim3(256), 0, st, W, N, chunks, wm);
@@ -1307,7 +1313,7 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
     return check_launch("combine");
   }
 #define HECKA_COMBINE(V, MD, F) \
-  hipLaunchKernelGGL((combine_kernel<V, MD, F>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN)
+  hipLaunchKernelGGL((combine_kernel<V, MD, F>), grid, dim3(kThreads), 0, st, g, gamma, B, detach_diag, W, tilesN, n_start)
   if (mode == 1) {
     if (full) HECKA_COMBINE(true, 1, true);
     else if (vec) HECKA_COMBINE(true, 1, false);
@@ -1329,6 +1335,13 @@ int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma
                       float* W, float* wmax, void* stream) {
   if (B <= 0) return fail(HECKA_EINVAL, "combine: non-positive size%s");
   return combine_impl(A, C, gamma, Ma, Mb, (long long)B * B, B, detach_diag, W, wmax, stream, 1);
+}
+
+int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma, int Ma, int Mb, int B,
+                            long long n_start, long long n_count, int detach_diag, float* Ws, void* stream) {
+  if (B <= 0 || n_start < 0 || n_count <= 0 || n_start + n_count > (long long)B * B)
+    return fail(HECKA_EINVAL, "combine_slice: the slice must lie inside the B*B Gram%s");
+  return combine_impl(A, Cs, gamma, Ma, Mb, n_count, B, detach_diag, Ws, nullptr, stream, 1, n_start);
 }
 
 int hecka_wbound_f32(const float* A, const float* nsq, const float* gamma, int Ma, int Mb, int B, float* wbound,

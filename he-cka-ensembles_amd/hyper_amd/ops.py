@@ -151,7 +151,6 @@ def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None):
     st = _stream()
     gamma = torch.empty((Ma, B), device=X.device, dtype=torch.float32)
     W = torch.empty((Ma, B, B), device=X.device, dtype=torch.float32)
-    dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), st), 'coef_gamma')
     wmax = torch.empty((Ma,), device=X.device, dtype=torch.float32) if xmax is not None else None
     bound = wmax is not None and nsq is not None
@@ -159,12 +158,55 @@ def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None):
         _lib.check(L.hecka_wbound_f32(_p(A), _p(nsq), _p(gamma), Ma, Mb, B, _p(wmax), st), 'wbound')
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W),
                                    _p(wmax) if wmax is not None and not bound else None, st), 'combine')
+    return gram_bwd_w(W, X, wmax, xmax)
+
+
+# --- the stages of gram_backward one by one, for the member-sharded path (hyper_amd/parallel.py), which runs the
+# combine on a column slice of every member's Gram and the dX GEMM on the local members' rows of W ---
+SLICE_GRANULE = 64   # column slices in multiples of the streaming combine kernel's 64-column chunks
+
+
+def coef_gamma(A, cvec):
+    """gamma [Ma,B] = A [Ma,Mb] @ cvec [Mb,B]."""
+    Ma, Mb = A.shape
+    B = cvec.shape[1]
+    gamma = torch.empty((Ma, B), device=A.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_coef_gamma_f32(_p(A), _p(cvec), Ma, Mb, B, _p(gamma), _stream()), 'coef_gamma')
+    return gamma
+
+
+def combine_slice(A, Cs, gamma, B, n_start, detach_diag):
+    """Ws [Ma,n] = elements [n_start, n_start + n) of every W_i = 2 sum_j A_ij C_j + gamma_i 1^T - 1 gamma_i^T
+    (diag masked) from the same elements Cs [Mb,n] of every C_j."""
+    Ma, Mb = A.shape
+    n = Cs.shape[1]
+    Ws = torch.empty((Ma, n), device=Cs.device, dtype=torch.float32)
+    if n:
+        _lib.check(_lib.lib().hecka_combine_slice_f32(_p(A), _p(Cs), _p(gamma), Ma, Mb, B, n_start, n,
+                                                      int(bool(detach_diag)), _p(Ws), _stream()), 'combine_slice')
+    return Ws
+
+
+def wbound(A, nsq, gamma):
+    """[Ma] upper bounds of max |W_i| (hecka_wbound_f32)."""
+    Ma, Mb = A.shape
+    out = torch.empty((Ma,), device=A.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_wbound_f32(_p(A), _p(nsq), _p(gamma), Ma, Mb, gamma.shape[1], _p(out), _stream()),
+               'wbound')
+    return out
+
+
+def gram_bwd_w(W, X, wmax=None, xmax=None):
+    """dX [Ma,B,P] = W [Ma,B,B] X."""
+    Ma, B, P = X.shape
+    dX = torch.empty_like(X)
     gate = _GemmChain.enter(X.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), _p(wmax) if wmax is not None else None,
-                                    _p(xmax) if xmax is not None else None, Ma, B, P, _p(dX), st), 'gram_bwd')
+    _lib.check(_lib.lib().hecka_gram_bwd_f32(_p(W), _p(X), _p(wmax) if wmax is not None else None,
+                                             _p(xmax) if xmax is not None else None, Ma, B, P, _p(dX), _stream()),
+               'gram_bwd')
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))

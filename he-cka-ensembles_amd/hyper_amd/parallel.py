@@ -6,24 +6,168 @@ The reference scales with DDP over the SAMPLE batch and evaluates the loss on ea
 are sharded: rank r owns members [r*M/G, (r+1)*M/G) on the FULL batch and the result equals the
 single-GPU loss and gradient up to reduction order.
 
-Per layer, one exchange step:
-    local   : C_loc, cvec_loc = centred Gram of the local members                      (MFMA)
-    exchange: all_gather(C_loc) -> C_all [M,B,B], all_gather(cvec_loc) -> cvec_all     (RCCL, async: overlaps
-              with the next layer's Gram)
-    local   : S_loc = <C_loc, C_all> [M/G, M];  nsq via a tiny all_gather of its diagonal
-              head -> partial loss; all_reduce(sum) of ONE scalar for all layers
-    backward: head_bwd on the local rows -> A_loc [M/G, M]; W_loc = combine(A_loc, C_all); dX_loc = W_loc X_loc
-No second exchange: row i of the coefficient matrix needs G_ij and G_ji, and G_ji = G_ij because cos is
-symmetric and the upstream of a mean/sum reduction is uniform (with detach_right only G_ij is used).
+Two exchange schemes (HECKA_SHARD_MODE = slice (default) | gather):
 
-`backend` is the object that provides the five device stages (default: hyper_amd.ops = libhecka).  The
-gloo/CPU tests inject an oracle-backed backend to check the sharding logic without a GPU; the product
-path never does."""
+slice - every stage's work AND the exchanged bytes per rank fall as 1/G.  After the local Grams, an
+    all-to-all re-partitions the [M, B*B] matrix of flattened Grams from member rows to COLUMN slices:
+    local   : C_loc [M/G, B*B], cvec_loc = centred Grams of the local members              (MFMA, 1/G of the flops)
+    exchange: all_to_all -> Cs [M, B*B/G] (this rank's slice of every member's Gram);      (M/G * B*B * 4 bytes out)
+              one all_gather of every layer's cvec (M*B floats per layer)
+    local   : S_part = Cs Cs^T [M, M] over the slice; ONE all_reduce of all layers' S_part   (L*M*M floats)
+              head on the full S (M*M elements, every rank the same: no exchange of the loss)
+    backward: head_bwd -> A [M, M] (every rank), gamma = A cvec; Ws = combine(A, Cs) on the slice   (1/G of HBM traffic)
+              all_to_all back -> W_loc [M/G, B*B]; dX_loc = W_loc X_loc                     (MFMA, 1/G of the flops)
+    The all-to-all of layer l runs behind the stages of layer l+1 (async work handles).
+gather - the first scheme: all_gather the local Grams to C_all [M, B, B] on every rank, S rows and W rows for the
+    local members against all of C_all.  One exchange, but M*B*B*4 bytes arrive at every rank whatever G is, and the
+    pairwise and combine stages do not shrink below reading all of C_all; kept for backends without the slice stages.
+
+`backend` is the object that provides the device stages (default: hyper_amd.ops = libhecka).  The gloo/CPU
+tests inject an oracle-backed backend to check the sharding logic without a GPU; the product path never
+does.  With the gloo backend and GPU tensors (a rehearsal of several ranks on one card) the collectives are
+staged through the host."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
-class _ShardedLayers(torch.autograd.Function):
+class _Done:
+    def wait(self):
+        return True
+
+
+def _staged(group, *ts):
+    return dist.get_backend(group) == 'gloo' and any(t.is_cuda for t in ts)
+
+
+def _all_to_all(out, inp, out_splits, in_splits, group):
+    if _staged(group, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return _Done()
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=True)
+
+
+def _all_gather(out, inp, group):
+    if _staged(group, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
+
+
+def _all_reduce(t, group):
+    if _staged(group, t):
+        o = t.cpu()
+        dist.all_reduce(o, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(o)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def slice_bounds(n, world, granule=1):
+    """world+1 boundaries of the column slices of a row of n Gram elements: multiples of `granule` when n is
+    (the streaming combine kernel works on 64-column chunks), as even as that allows."""
+    q = granule if granule > 0 and n % granule == 0 else 1
+    units = n // q
+    return [((g * units) // world) * q for g in range(world + 1)]
+
+
+class _SlicedLayers(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, *feats):
+        backend, group, specs, weights, detach, reduce = cfg
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        Ml, B = feats[0].shape[0], feats[0].shape[1]
+        M, r0, N2 = Ml * world, rank * Ml, B * B
+        bounds = slice_bounds(N2, world, getattr(backend, 'SLICE_GRANULE', 1))
+        ns = [bounds[g + 1] - bounds[g] for g in range(world)]
+        n_r = ns[rank]
+        feats = [X.contiguous() for X in feats]
+        multi = getattr(backend, 'multi_gram_eligible', None)
+        pre = backend.centered_gram_multi(feats) if multi is not None and multi(feats) else None
+        slices, cvecs, xmaxs = [], [], []
+        for li, X in enumerate(feats):
+            if X.shape[0] != Ml or X.shape[1] != B:
+                raise ValueError('every layer needs the same members and samples')
+            C, cvec, xmax = pre[li] if pre is not None else backend.centered_gram(X, True)
+            C2 = C.reshape(Ml, N2)
+            if world == 1:
+                slices.append((C2, _Done()))
+            else:
+                send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
+                Cs = torch.empty((M, n_r), device=C.device, dtype=C.dtype)
+                slices.append((Cs, _all_to_all(Cs.view(-1), send, [Ml * n_r] * world, [Ml * n for n in ns], group)))
+            cvecs.append(cvec)
+            xmaxs.append(xmax)
+        L = len(feats)
+        cv_loc = torch.stack(cvecs)                                              # [L, Ml, B]
+        if world == 1:
+            cv_all = cv_loc
+        else:
+            raw = torch.empty((world, L, Ml, B), device=cv_loc.device, dtype=cv_loc.dtype)
+            _all_gather(raw.view(-1), cv_loc.view(-1), group).wait()
+            cv_all = raw.permute(1, 0, 2, 3).reshape(L, M, B).contiguous()
+        parts = []
+        for Cs, work in slices:
+            work.wait()
+            parts.append(backend.pairwise_inner(Cs) if n_r else
+                         torch.zeros((M, M), device=Cs.device, dtype=Cs.dtype))
+        S_all = torch.stack(parts)                                               # [L, M, M]
+        if world > 1:
+            _all_reduce(S_all, group)
+        total, saved = None, []
+        for li, (X, spec, wl) in enumerate(zip(feats, specs, weights)):
+            S = S_all[li]
+            nsq = torch.diagonal(S).contiguous()
+            count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
+            scale = float(wl) / count if count else float('nan')
+            _, part = backend.head_forward(S, nsq, 0, spec, scale)
+            total = part if total is None else total + part
+            saved.append((X, slices[li][0], cv_all[li], S, nsq, spec, scale, xmaxs[li]))
+        ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
+        ctx.geom = (world, rank, Ml, B, bounds, ns)
+        return total.clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        be, group = ctx.backend, ctx.group
+        world, rank, Ml, B, bounds, ns = ctx.geom
+        r0, n_r, N2 = rank * Ml, ns[rank], B * B
+        dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
+        pending = []
+        for X, Cs, cv_all, S, nsq, spec, scale, xmax in ctx.saved:
+            A = be.head_backward(S, nsq, 0, spec, dloss, scale)                  # [M, M], the same on every rank
+            gamma = be.coef_gamma(A, cv_all)                                     # [M, B]
+            Ws = be.combine_slice(A, Cs, gamma, B, bounds[rank], ctx.detach)     # [M, n_r]
+            if world == 1:
+                recv, work = Ws, _Done()
+            else:
+                recv = torch.empty((Ml * N2,), device=Ws.device, dtype=Ws.dtype)
+                work = _all_to_all(recv, Ws.view(-1), [Ml * n for n in ns], [Ml * n_r] * world, group)
+            wmax = None
+            if xmax is not None and hasattr(be, 'wbound'):
+                wmax = be.wbound(A[r0:r0 + Ml].contiguous(), nsq, gamma[r0:r0 + Ml].contiguous())
+            pending.append((X, recv, work, wmax, xmax))
+        grads = []
+        for X, recv, work, wmax, xmax in pending:
+            work.wait()
+            if world == 1:
+                W = recv
+            else:
+                W = torch.empty((Ml, N2), device=recv.device, dtype=recv.dtype)
+                off = 0
+                for g in range(world):
+                    W[:, bounds[g]:bounds[g + 1]] = recv[off:off + Ml * ns[g]].view(Ml, ns[g])
+                    off += Ml * ns[g]
+            grads.append(be.gram_bwd_w(W.view(Ml, B, B), X, wmax, xmax))
+        return (None,) + tuple(grads)
+
+
+class _GatheredLayers(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, *feats):
         backend, group, specs, weights, detach, reduce = cfg
@@ -40,8 +184,7 @@ class _ShardedLayers(torch.autograd.Function):
             C, cvec, xmax = pre[li] if pre is not None else backend.centered_gram(X, True)   # xmax: max |X| (dX scaling)
             C_all = torch.empty((M,) + tuple(C.shape[1:]), device=C.device, dtype=C.dtype)
             cv_all = torch.empty((M, cvec.shape[1]), device=C.device, dtype=C.dtype)
-            works.append((dist.all_gather_into_tensor(C_all, C, group=group, async_op=True),
-                          dist.all_gather_into_tensor(cv_all, cvec, group=group, async_op=True)))
+            works.append((_all_gather(C_all, C, group), _all_gather(cv_all, cvec, group)))
             grams.append((X, C, C_all, cv_all, xmax))
         total = None
         saved = []
@@ -51,25 +194,34 @@ class _ShardedLayers(torch.autograd.Function):
             S = backend.pairwise_inner(C, C_all)                        # [Ml, M]
             nsq_loc = torch.diagonal(S, offset=r0).contiguous()          # S[i, r0+i]
             nsq = torch.empty((M,), device=S.device, dtype=S.dtype)
-            dist.all_gather_into_tensor(nsq, nsq_loc, group=group)
+            _all_gather(nsq, nsq_loc, group).wait()
             count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
-            scale = float(wl) / count
+            scale = float(wl) / count if count else float('nan')
             _, part = backend.head_forward(S, nsq, r0, spec, scale)
             total = part if total is None else total + part
             saved.append((X, C_all, cv_all, S, nsq, spec, scale, xmax))
         total = total.clone()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(total, group)
         ctx.saved, ctx.backend, ctx.r0, ctx.detach = saved, backend, r0, detach
         return total
 
     @staticmethod
     def backward(ctx, dloss):
-        dloss = dloss.contiguous().float()
+        dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
         grads = []
         for X, C_all, cv_all, S, nsq, spec, scale, xmax in ctx.saved:
             A = ctx.backend.head_backward(S, nsq, ctx.r0, spec, dloss, scale)
             grads.append(ctx.backend.gram_backward(A, C_all, cv_all, X, ctx.detach, xmax))
         return (None,) + tuple(grads)
+
+
+def shard_mode(backend):
+    mode = os.environ.get('HECKA_SHARD_MODE', 'slice')
+    if mode not in ('slice', 'gather'):
+        raise ValueError("HECKA_SHARD_MODE must be 'slice' or 'gather'")
+    if mode == 'slice' and not all(hasattr(backend, f) for f in ('coef_gamma', 'combine_slice', 'gram_bwd_w')):
+        return 'gather'
+    return mode
 
 
 def sharded_layers_loss(feats, specs, weights, detach_diag=True, reduce='mean', group=None, backend=None):
@@ -79,7 +231,8 @@ def sharded_layers_loss(feats, specs, weights, detach_diag=True, reduce='mean', 
         from . import ops as backend
     if reduce not in ('mean', 'sum'):
         raise ValueError("the sharded loss supports reduction 'mean' or 'sum'")
-    return _ShardedLayers.apply((backend, group, list(specs), list(weights), bool(detach_diag), reduce), *feats)
+    fn = _SlicedLayers if shard_mode(backend) == 'slice' else _GatheredLayers
+    return fn.apply((backend, group, list(specs), list(weights), bool(detach_diag), reduce), *feats)
 
 
 class ShardedModelLayersKernel(torch.nn.Module):

@@ -117,6 +117,14 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
 int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B,
                       int detach_diag, float* W, float* wmax, void* stream);
 
+/* hecka_combine_f32 on a column slice of the flattened Gram: Cs [Mb, n_count] holds the elements
+ * [n_start, n_start + n_count) of every C_j (row-major B*B), Ws [Ma, n_count] receives the same elements of every W_i.
+ * For the member-sharded multi-GPU path (hyper_amd/parallel.py), where rank r holds a B*B/G slice of ALL members'
+ * Grams after the all-to-all; the reference has no counterpart (it scales with DDP over samples,
+ * hyper/experiments/training.py:686-695). */
+int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma, int Ma, int Mb, int B,
+                            long long n_start, long long n_count, int detach_diag, float* Ws, void* stream);
+
 /* Upper bound of max |W_i| from what already exists: wbound[i] = 2 sum_j |A[i,j]| sqrt(nsq[j]) + 2 max_b |gamma[i,b]|
  * (nsq[j] = ||C_j||_F^2, the diagonal of hecka_pairwise_f32's S).  Accepted by hecka_gram_bwd_f32 in place of the exact
  * maximum (a looser power-of-two scale only lowers the fp16 low plane's subnormal floor), so callers that have nsq pass

@@ -67,3 +67,22 @@ def gram_backward(A, C_all, cv_all, X, detach_diag, xmax=None):
     if detach_diag:
         W = W * (1.0 - np.eye(B))[None]
     return _t(np.einsum('mab,mbp->map', W, Xn)).to(X.dtype)
+
+
+# the stages of the column-sliced scheme (hyper_amd.parallel._SlicedLayers)
+def coef_gamma(A, cvec):
+    return A @ cvec
+
+
+def combine_slice(A, Cs, gamma, B, n_start, detach_diag):
+    n = np.arange(n_start, n_start + Cs.shape[1])
+    a, b = n // B, n % B
+    g = gamma.numpy()
+    W = 2.0 * (A.numpy() @ Cs.numpy()) + g[:, a] - g[:, b]
+    if detach_diag:
+        W[:, a == b] = 0.0
+    return _t(W)
+
+
+def gram_bwd_w(W, X, wmax=None, xmax=None):
+    return _t(np.einsum('mab,mbp->map', W.numpy(), X.double().numpy())).to(X.dtype)

@@ -1,0 +1,101 @@
+"""GPU tests of the member-sharded path (hyper_amd.parallel) with the real kernels.
+
+* hecka_combine_slice_f32 on column slices against the same columns of hecka_combine_f32.
+* Two / four ranks rehearsed on ONE card: one process per rank, gloo rendezvous (RCCL refuses two ranks on one
+  device; parallel.py stages the collectives through the host for gloo), every stage on the GPU through libhecka.
+  Loss and gradients must equal the unsharded hyper_amd result to the parity tolerance (rel 1e-5)."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-5
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize('M,B', [(64, 128), (32, 64), (12, 40), (5, 7)])
+def test_combine_slice_equals_full_combine(M, B):
+    """M = 64 takes the streaming kernel (64-column chunks, chunk0 != 0), the others the tiled kernel."""
+    from hyper_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    A = torch.randn(M, M, device=dev) / M
+    C = torch.randn(M, B, B, device=dev)
+    gamma = torch.randn(M, B, device=dev)
+    W = torch.empty(M, B, B, device=dev)
+    L = _lib.lib()
+    _lib.check(L.hecka_combine_f32(A.data_ptr(), C.data_ptr(), gamma.data_ptr(), M, M, B, 1, W.data_ptr(), None,
+                                   torch.cuda.current_stream().cuda_stream), 'combine')
+    N2 = B * B
+    from hyper_amd.parallel import slice_bounds
+    for world in (1, 2, 3, 8):
+        bounds = slice_bounds(N2, world, ops.SLICE_GRANULE)
+        assert bounds[0] == 0 and bounds[-1] == N2
+        for g in range(world):
+            s, e = bounds[g], bounds[g + 1]
+            Cs = C.view(M, N2)[:, s:e].contiguous()
+            Ws = ops.combine_slice(A, Cs, gamma, B, s, True)
+            assert Ws.shape == (M, e - s)
+            if e > s:
+                assert torch.equal(Ws, W.view(M, N2)[:, s:e]), (world, g)
+
+
+def _case(name):
+    torch.manual_seed(17)
+    M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9))}[name]
+    feats = [torch.randn(M, B, p) * (1.0 + 0.5 * i) for i, p in enumerate(Ps)]
+    cfg = {'name': 'model_layers', 'reduction': 'mean',
+           'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031,
+                            'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}},
+           'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2, 0.7][:len(Ps)]}}
+    return cfg, feats
+
+
+def _worker(rank, world, port, name, out, mode):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from hyper_amd.parallel import ShardedModelLayersKernel
+    dev = torch.device('cuda:0')
+    cfg, feats = _case(name)
+    Ml = feats[0].shape[0] // world
+    xs = [f[rank * Ml:(rank + 1) * Ml].to(dev).requires_grad_(True) for f in feats]
+    kern = ShardedModelLayersKernel(build_model_kernel(cfg).to(dev))
+    loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.save({'loss': loss.detach().cpu(), 'grads': [x.grad.cpu() for x in xs]}, '%s.%d' % (out, rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world,mode', [('m64', 2, 'slice'), ('m64', 4, 'slice'), ('m12', 3, 'slice'),
+                                             ('m64', 2, 'gather')])
+def test_ranks_on_one_card_match_unsharded(name, world, mode, tmp_path):
+    import torch.multiprocessing as mp
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    dev = torch.device('cuda:0')
+    cfg, feats = _case(name)
+    xs = [f.to(dev).requires_grad_(True) for f in feats]
+    ref = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+    ref.backward()
+    out = str(tmp_path / 'res')
+    port = 29950 + (os.getpid() + 11 * world + len(name) + len(mode)) % 200
+    mp.start_processes(_worker, args=(world, port, name, out, mode), nprocs=world, join=True, start_method='spawn')
+    Ml = feats[0].shape[0] // world
+    for r in range(world):
+        res = torch.load('%s.%d' % (out, r), weights_only=True)
+        assert abs(res['loss'].item() - ref.item()) <= RTOL * abs(ref.item())
+        for g, x in zip(res['grads'], xs):
+            assert _relerr(g.numpy(), x.grad[r * Ml:(r + 1) * Ml].cpu().numpy()) <= RTOL

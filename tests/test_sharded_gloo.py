@@ -12,9 +12,9 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, cfgname, out):
+def _worker(rank, world, port, cfgname, out, mode):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import cpu_backend
     from hyper_amd.diversity.model_kernels import build_model_kernel
@@ -33,8 +33,9 @@ def _worker(rank, world, port, cfgname, out):
 
 def _case(name):
     torch.manual_seed(21)
-    feats = [torch.randn(6, 12, p, dtype=torch.float64) for p in (9, 20)]
-    lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031),
+    B = 5 if name == 'he_uneven' else 12      # B*B = 25 does not split evenly: slices of 12/13 and 8/8/9 elements
+    feats = [torch.randn(6, B, p, dtype=torch.float64) for p in (9, 20)]
+    lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031), 'he_uneven': dict(name='he', eps=0.0025, arc_eps=0.031),
           'he_exp_dr': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True, detach_right=True),
           'cka': dict(name='cka', eps=1e-6)}[name]
     lk['feature_kernel'] = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
@@ -43,13 +44,14 @@ def _case(name):
     return cfg, feats
 
 
-@pytest.mark.parametrize('name', ['he', 'he_exp_dr', 'cka'])
+@pytest.mark.parametrize('name', ['he', 'he_exp_dr', 'cka', 'he_uneven'])
 @pytest.mark.parametrize('world', [2, 3])
-def test_sharded_matches_single_process_oracle(name, world, tmp_path):
+@pytest.mark.parametrize('mode', ['slice', 'gather'])
+def test_sharded_matches_single_process_oracle(name, world, mode, tmp_path):
     from oracle import hecka_ref as R
     out = str(tmp_path / 'res')
-    port = 29600 + (os.getpid() + world * 7 + len(name)) % 300
-    mp.start_processes(_worker, args=(world, port, name, out), nprocs=world, join=True, start_method='spawn')
+    port = 29600 + (os.getpid() + world * 7 + len(name) + 13 * len(mode)) % 300
+    mp.start_processes(_worker, args=(world, port, name, out, mode), nprocs=world, join=True, start_method='spawn')
     cfg, feats = _case(name)
     xo = [f.clone().requires_grad_(True) for f in feats]
     ref = R.run_config(cfg, xo)
@@ -61,3 +63,13 @@ def test_sharded_matches_single_process_oracle(name, world, tmp_path):
         for g, x in zip(res['grads'], xo):
             exp = x.grad[r * Ml:(r + 1) * Ml]
             assert np.abs(g.numpy() - exp.numpy()).max() <= 1e-9 * np.abs(exp.numpy()).max()
+
+
+def test_slice_bounds():
+    from hyper_amd.parallel import slice_bounds
+    assert slice_bounds(512 * 512, 8, 64) == [i * 32768 for i in range(9)]
+    assert slice_bounds(25, 3) == [0, 8, 16, 25]
+    b = slice_bounds(40 * 40, 3, 64)                       # 25 chunks of 64 over 3 ranks
+    assert b[0] == 0 and b[-1] == 1600 and all(x % 64 == 0 for x in b) and b == sorted(b)
+    assert slice_bounds(7 * 7, 2, 64) == [0, 24, 49]        # not a multiple of the granule: element granularity
+    assert slice_bounds(64, 4, 64) == [0, 0, 0, 0, 64]      # fewer chunks than ranks: empty slices
