@@ -86,6 +86,7 @@ class _SlicedLayers(torch.autograd.Function):
         bounds = slice_bounds(N2, world, getattr(backend, 'SLICE_GRANULE', 1))
         ns = [bounds[g + 1] - bounds[g] for g in range(world)]
         n_r = ns[rank]
+        even = all(n == n_r for n in ns)
         feats = [X.contiguous() for X in feats]
         multi = getattr(backend, 'multi_gram_eligible', None)
         pre = backend.centered_gram_multi(feats) if multi is not None and multi(feats) else None
@@ -98,7 +99,10 @@ class _SlicedLayers(torch.autograd.Function):
             if world == 1:
                 slices.append((C2, _Done()))
             else:
-                send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
+                if even:      # [Ml, G, n] -> [G, Ml, n] in one strided copy
+                    send = C2.view(Ml, world, n_r).permute(1, 0, 2).contiguous().view(-1)
+                else:
+                    send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
                 Cs = torch.empty((M, n_r), device=C.device, dtype=C.dtype)
                 slices.append((Cs, _all_to_all(Cs.view(-1), send, [Ml * n_r] * world, [Ml * n for n in ns], group)))
             cvecs.append(cvec)
@@ -157,6 +161,8 @@ class _SlicedLayers(torch.autograd.Function):
             work.wait()
             if world == 1:
                 W = recv
+            elif all(n == n_r for n in ns):      # [G, Ml, n] -> [Ml, G, n] in one strided copy
+                W = recv.view(world, Ml, n_r).permute(1, 0, 2).contiguous()
             else:
                 W = torch.empty((Ml, N2), device=recv.device, dtype=recv.dtype)
                 off = 0
