@@ -55,6 +55,34 @@ __device__ __forceinline__ void split2h(const f32x4& v, int q0, V& vh, V& vl, in
   vl[qo] = __builtin_bit_cast(unsigned, l);
 }
 
+// Operand element kinds.  16-bit operands (bf16 / fp16 features) are loaded as they lie in HBM (half the bytes) and
+// widened to fp32 in registers right before the prologue; everything behind that is the fp32 pipeline.
+constexpr int kElemF32 = 0, kElemBF16 = 1, kElemF16 = 2;
+template <int E> constexpr int elem_bytes() { return E == kElemF32 ? 4 : 2; }
+template <int E>
+__device__ __forceinline__ float widen16(unsigned u) {   // low 16 bits of u
+  if (E == kElemBF16) return __uint_as_float(u << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)u);
+}
+// A staged quad of a 16-bit operand sits in the fp32 register set as raw bits: two packed dwords in v[0], v[1] (k
+// contiguous loads) or four zero-extended halves (GATHER: the transposing loads of an NN operand).
+template <int E, bool GATHER>
+__device__ __forceinline__ void widen_quad(f32x4& v) {
+  if (E == kElemF32) return;
+  if (GATHER) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = widen16<E>(__float_as_uint(v[e]));
+  } else {
+    const unsigned u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]);
+    if (E == kElemBF16) {
+      v = f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
+                __uint_as_float(u1 & 0xFFFF0000u)};
+    } else {
+      v = f32x4{widen16<E>(u0), widen16<E>(u0 >> 16), widen16<E>(u1), widen16<E>(u1 >> 16)};
+    }
+  }
+}
+
 // power-of-two scale s with bound * s <= 2^headroom (exact to apply and to undo); 1 for zero / non-finite bounds
 __device__ __forceinline__ float pow2_scale(float bound, int headroom) {
   const unsigned b = __float_as_uint(bound) & 0x7FFFFFFFu;
@@ -86,8 +114,13 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
 // Pro: transform of the staged fp32 values (centring), NT only.
 // FOLD = false: one accumulation chain over the whole K (no local chains, 64 fewer VGPRs: a third workgroup per CU);
 // only for short K - the 16-bit MFMA's truncation bias grows with the chain (about -5e-10 of sum|a.b| per k).
-template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true>
+// EA / EB: element kinds of the operands in HBM.  BLOW = false (f16x3 only): the staged B values are exact in ONE fp16
+// term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
+template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
+          bool BLOW = true>
 struct GemmTileX6 {
+  static_assert(BLOW || SCHEME == 1, "single-plane B operand: f16x3 only");
+  static constexpr int SA = elem_bytes<EA>(), SB = elem_bytes<EB>();
   static constexpr int NP = SCHEME == 1 ? 2 : 3;
   static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
   static constexpr int CA = TM * 4 / kThreads, CB = TN * 4 / kThreads;  // 4-k quads staged per thread per tile
@@ -96,7 +129,7 @@ struct GemmTileX6 {
   f32x16 acc[MI][NI];
 
   // Ab / Bb: this member's operands, bytesA / bytesB their sizes (< 4 GiB: offsets are 32-bit)
-  __device__ __forceinline__ void run(Smem& sm, const float* Ab, unsigned bytesA, int lda, const float* Bb,
+  __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb,
                                       unsigned bytesB, int ldb, int row0, int col0, int kbeg, int kend, Pro& pro) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
@@ -113,26 +146,34 @@ struct GemmTileX6 {
     // a resource descriptor, the tile/k position in a scalar byte offset, the thread's place in ONE 32-bit VGPR
     // offset per quad - no 64-bit address arithmetic in the loop.
     const int kq = t & 3, srow = t >> 2;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bb), 0, (int)bytesB, 0x00020000);
-    const unsigned sA0 = ((unsigned)row0 * lda + kbeg) * 4u;
-    const unsigned sB0 = NN ? ((unsigned)kbeg * ldb + col0) * 4u : ((unsigned)col0 * ldb + kbeg) * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Ab), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bb), 0, (int)bytesB, 0x00020000);
+    const unsigned sA0 = ((unsigned)row0 * lda + kbeg) * (unsigned)SA;
+    const unsigned sB0 = (NN ? ((unsigned)kbeg * ldb + col0) : ((unsigned)col0 * ldb + kbeg)) * (unsigned)SB;
     unsigned aoff[CA], bgoff[CB];
 #pragma unroll
-    for (int i = 0; i < CA; ++i) aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * 4u;
+    for (int i = 0; i < CA; ++i) aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * (unsigned)SA;
 #pragma unroll
     for (int i = 0; i < CB; ++i)
-      bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) * 4u;
+      bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) *
+                 (unsigned)SB;
     const int ntiles = (kend - kbeg) / kX6BK;
     if (ntiles <= 0) return;
 
     f32x4 ra[2][CA], rb[2][CB];  // two register sets: tiles t+1 and t+2 in flight
     auto gload_a = [&](auto SET, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(SET)::value;
-      const unsigned so = sA0 + (unsigned)kt * (kX6BK * 4u);
+      const unsigned so = sA0 + (unsigned)kt * (unsigned)(kX6BK * SA);
 #pragma unroll
-      for (int i = 0; i < CA; ++i)
-        ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[i], (int)so, 0));
+      for (int i = 0; i < CA; ++i) {
+        if (EA == kElemF32) {
+          ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[i], (int)so, 0));
+        } else {
+          const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)aoff[i], (int)so, 0);
+          ra[S][i][0] = __uint_as_float(r[0]);
+          ra[S][i][1] = __uint_as_float(r[1]);
+        }
+      }
     };
     auto gload_b = [&](auto SET, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(SET)::value;
@@ -141,12 +182,22 @@ struct GemmTileX6 {
       for (int i = 0; i < CB; ++i) {
         if (NN) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                rsB, (int)bgoff[i], (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * 4u), 0));
+          for (int c = 0; c < 4; ++c) {
+            const int so = (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * (unsigned)SB);
+            if (EB == kElemF32)
+              rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)bgoff[i], so, 0));
+            else
+              rb[S][i][c] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsB, (int)bgoff[i], so, 0));
+          }
         } else {
-          rb[S][i] = __builtin_bit_cast(
-              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[i], (int)(sB0 + (unsigned)kt * (kX6BK * 4u)), 0));
+          const int so = (int)(sB0 + (unsigned)kt * (unsigned)(kX6BK * SB));
+          if (EB == kElemF32) {
+            rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[i], so, 0));
+          } else {
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)bgoff[i], so, 0);
+            rb[S][i][0] = __uint_as_float(r[0]);
+            rb[S][i][1] = __uint_as_float(r[1]);
+          }
         }
       }
     };
@@ -160,6 +211,7 @@ struct GemmTileX6 {
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
         u32x2 p[3];
+        widen_quad<EA, false>(ra[S][i]);
         pro.stageA(SET, ra[S][i], i);
         if (SCHEME == 1) {
           split2h(ra[S][i], 0, p[0], p[1], 0);
@@ -177,6 +229,7 @@ struct GemmTileX6 {
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         u32x2 p[3];
+        widen_quad<EB, NN>(rb[S][i]);
         pro.stageB(SET, rb[S][i], i);
         if (SCHEME == 1) {
           split2h(rb[S][i], 0, p[0], p[1], 0);
@@ -186,7 +239,7 @@ struct GemmTileX6 {
           split2(rb[S][i], 2, p[0], p[1], p[2], 1);
         }
 #pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][boff[i]]) = p[q];
+        for (int q = 0; q < (BLOW ? NP : 1); ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][boff[i]]) = p[q];
       }
     };
 
@@ -256,7 +309,8 @@ struct GemmTileX6 {
           f32x4& src = isA ? ra[S][quad] : rb[S][quad];
           if (more) {
             if (step == 0) {
-              if (isA) pro.stageA(NSET, src, quad); else pro.stageB(NSET, src, quad);
+              if (isA) { widen_quad<EA, false>(src); pro.stageA(NSET, src, quad); }
+              else { widen_quad<EB, NN>(src); pro.stageB(NSET, src, quad); }
               split2(src, 0, qv[0], qv[1], qv[2], 0);
             } else if (step == 1) {
               split2(src, 2, qv[0], qv[1], qv[2], 1);
@@ -287,9 +341,11 @@ struct GemmTileX6 {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+        if (p == 0 || BLOW) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          fb[j][p] = *reinterpret_cast<const f16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+          for (int j = 0; j < NI; ++j)
+            fb[j][p] = *reinterpret_cast<const f16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       constexpr int PA[3] = {0, 0, 1};
@@ -298,7 +354,7 @@ struct GemmTileX6 {
 #pragma unroll
       for (int n = 0; n < 12; ++n) {
         const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        {
+        if (BLOW || e != 1) {   // e = 1 is A.h x B.l
           if (FOLD) {
             f32x16 c = loc[i][j];
             if (decltype(FIRST)::value && e == 0) {
@@ -319,14 +375,15 @@ struct GemmTileX6 {
           f32x4& src = isA ? ra[S][quad] : rb[S][quad];
           if (more) {
             if (step == 0) {
-              if (isA) pro.stageA(NSET, src, quad); else pro.stageB(NSET, src, quad);
+              if (isA) { widen_quad<EA, false>(src); pro.stageA(NSET, src, quad); }
+              else { widen_quad<EB, NN>(src); pro.stageB(NSET, src, quad); }
               split2h(src, 0, qv[0], qv[1], 0);
               split2h(src, 2, qv[0], qv[1], 1);
             } else {
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
                 if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q];
-                else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
+                else if (q == 0 || BLOW) *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
               }
             }
           }

@@ -35,6 +35,50 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ------------------------------------------------------------------------------------------
 // Optional side output xmax[m] = max |X[m]| (bit pattern of a non-negative float, combined with atomicMax; the
 // caller zeroes it): the fp16-split GEMMs scale their operands by a power of two derived from it.
+// 16-bit features (bf16 / fp16): four columns = one 8-byte load, widened in registers; P % 4 == 0, 8-byte aligned.
+template <int E>
+__global__ __launch_bounds__(512) void colmean16_kernel(const unsigned short* __restrict__ X, int B, int P,
+                                                        float* __restrict__ sbar, unsigned* __restrict__ xmax) {
+  __shared__ f32x4 red[16][32];
+  __shared__ float wred[8];
+  float mx = 0.f;
+  const int m = blockIdx.y;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int p = (blockIdx.x * 32 + cx) * 4;
+  const unsigned short* Xm = X + (size_t)m * B * P;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (p < P) {
+#pragma unroll 8
+    for (int b = ry; b < B; b += 16) {
+      const u32x2 r = *reinterpret_cast<const u32x2*>(Xm + (size_t)b * P + p);
+      f32x4 v;
+      v[0] = __uint_as_float(r[0]);
+      v[1] = __uint_as_float(r[1]);
+      widen_quad<E, false>(v);
+      acc += v;
+      mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mx;
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = wred[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = fmaxf(v, wred[w]);
+    atomicMax(xmax + m, __float_as_uint(v));
+  }
+  if (ry == 0 && p < P) {
+    f32x4 s = red[0][cx];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) s += red[r][cx];
+    const float inv = 1.0f / (float)B;
+    *reinterpret_cast<f32x4*>(sbar + (size_t)m * P + p) = s * inv;
+  }
+}
+
 template <bool VEC, bool AMAX>
 __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
                                                       float* __restrict__ sbar, unsigned* __restrict__ xmax) {
@@ -223,12 +267,13 @@ struct CenterProX6 {
   template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
 
-template <int SCHEME>
-__device__ __forceinline__ void gram_center_x6_body(const float* __restrict__ X, const float* __restrict__ sbar,
+template <int SCHEME, int EX = kElemF32>
+__device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
                                                     int w) {
-  using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME>;
+  using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX>;
+  constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
   int m, rem;
@@ -239,14 +284,14 @@ __device__ __forceinline__ void gram_center_x6_body(const float* __restrict__ X,
     ++I;
   }
   const int J = I + rem;
-  const float* Xm = X + (size_t)m * B * P;
+  const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * ES;
   CenterProX6<SCHEME> pro;
   pro.sbar = sbar + (size_t)m * P;
   pro.s = SCHEME == 1 ? pow2_scale(xmax[m], 13) : 1.0f;
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float unscale = SCHEME == 1 ? 1.0f / (pro.s * pro.s) : 1.0f;
   Tile tile;
-  tile.run(sm, Xm, (unsigned)B * P * 4u, P, Xm, (unsigned)B * P * 4u, P, I * 128, J * 128, 0, P, pro);
+  tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
   // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -284,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float
 // layer's last workgroups go to the next layer's first ones and only the launch's very end is ragged.
 constexpr int kMaxGramLayers = 16;
 struct GramLayerArgs {
-  const float* X;
+  const void* X;
   const float* sbar;
   const float* xmax;
   float* C;
@@ -297,7 +342,7 @@ struct GramMultiArgs {
   int L;
 };
 
-template <int SCHEME>
+template <int SCHEME, int EX = kElemF32>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
   const int w = blockIdx.x;
   int li = 0, w0 = 0;
@@ -306,12 +351,12 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
     ++li;
   }
   // (kernel-argument struct indexed with a runtime index: copy the selected layer's fields through scalar selects)
-  const float* X = a.l[0].X; const float* sbar = a.l[0].sbar; const float* xmax = a.l[0].xmax;
+  const void* X = a.l[0].X; const float* sbar = a.l[0].sbar; const float* xmax = a.l[0].xmax;
   float* C = a.l[0].C; float* cvec = a.l[0].cvec; int P = a.l[0].P;
 #pragma unroll
   for (int i = 1; i < kMaxGramLayers; ++i)
     if (i == li) { X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P; }
-  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
+  gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -591,13 +636,16 @@ struct ScaleProX6 {
   }
 };
 
-template <int SCHEME, bool FOLD = true>
-__global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const float* __restrict__ X,
+// EX: element kind of X and dX.  16-bit features times the power-of-two scale are exact in one fp16 term, so X has no
+// low plane (two products per multiply instead of three) and dX is rounded once, to the feature type, on the way out.
+template <int SCHEME, bool FOLD = true, int EX = kElemF32>
+__global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
                                                                   const unsigned* __restrict__ wmax,
                                                                   const float* __restrict__ xmax,
-                                                                  float* __restrict__ dX, int B, int P, int tilesM,
+                                                                  void* __restrict__ dX, int B, int P, int tilesM,
                                                                   int tilesN, int xcd_map) {
-  using Tile = GemmTileX6<128, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD>;
+  using Tile = GemmTileX6<128, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32>;
+  constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
   member_tile(tilesM * tilesN, xcd_map, m, tl);
@@ -607,11 +655,14 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(con
   pro.sb = SCHEME == 1 ? pow2_scale(xmax[m], 14) : 1.0f;
   const float unscale = SCHEME == 1 ? 1.0f / (pro.sa * pro.sb) : 1.0f;
   Tile tile;
-  tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, X + (size_t)m * B * P, (unsigned)B * P * 4u, P, ti * 128,
-           tj * 128, 0, B, pro);
-  float* out = dX + (size_t)m * B * P;
+  tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
+           (unsigned)B * P * ES, P, ti * 128, tj * 128, 0, B, pro);
   tile.for_each([&](int lr, int lc, float v) {
-    out[(size_t)(ti * 128 + lr) * P + tj * 128 + lc] = SCHEME == 1 ? v * unscale : v;
+    const size_t idx = (size_t)m * B * P + (size_t)(ti * 128 + lr) * P + tj * 128 + lc;
+    const float r = SCHEME == 1 ? v * unscale : v;
+    if (EX == kElemF32) static_cast<float*>(dX)[idx] = r;
+    else if (EX == kElemBF16) static_cast<__bf16*>(dX)[idx] = (__bf16)r;
+    else static_cast<_Float16*>(dX)[idx] = (_Float16)r;
   });
 }
 
@@ -1159,6 +1210,26 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* x
   return check_launch("colmean");
 }
 
+int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar, float* xmax, void* stream) {
+  if (dtype == HECKA_DT_F32) return hecka_colmean_f32(static_cast<const float*>(X), M, B, P, sbar, xmax, stream);
+  clear_error();
+  if (dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) return fail(HECKA_EINVAL, "colmean_x16: unknown dtype%s");
+  if (!X || !sbar || !xmax) return fail(HECKA_EINVAL, "colmean_x16: null pointer%s");
+  if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "colmean_x16: bad size%s");
+  if (P % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 7) || !aligned16(sbar))
+    return fail(HECKA_EINVAL, "colmean_x16: needs P %% 4 == 0 and aligned rows (P = %lld)%s", "", P);
+  dim3 grid((P + 127) / 128, M);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* xm = reinterpret_cast<unsigned*>(xmax);
+  if (hipMemsetAsync(xm, 0, (size_t)M * sizeof(unsigned), st) != hipSuccess) return check_launch("colmean_x16 (memset)");
+  const unsigned short* X16 = static_cast<const unsigned short*>(X);
+  if (dtype == HECKA_DT_BF16)
+    hipLaunchKernelGGL(colmean16_kernel<kElemBF16>, grid, dim3(512), 0, st, X16, B, P, sbar, xm);
+  else
+    hipLaunchKernelGGL(colmean16_kernel<kElemF16>, grid, dim3(512), 0, st, X16, B, P, sbar, xm);
+  return check_launch("colmean_x16");
+}
+
 int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P, float* C,
                           float* cvec, void* stream) {
   clear_error();
@@ -1195,9 +1266,31 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
   return check_launch("gram_center");
 }
 
+static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
+                                  const float* const* xmax, int M, int B, const int* P, float* const* C,
+                                  float* const* cvec, void* stream);
+
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
                                 int B, const int* P, float* const* C, float* const* cvec, void* stream) {
+  return gram_center_multi_impl(L, reinterpret_cast<const void* const*>(X), HECKA_DT_F32, sbar, xmax, M, B, P, C, cvec,
+                                stream);
+}
+
+int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
+                                const float* const* xmax, int M, int B, const int* P, float* const* C,
+                                float* const* cvec, void* stream) {
+  if (dtype != HECKA_DT_F32 && dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) {
+    clear_error();
+    return fail(HECKA_EINVAL, "gram_center_multi_x16: unknown dtype%s");
+  }
+  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, stream);
+}
+
+static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
+                                  const float* const* xmax, int M, int B, const int* P, float* const* C,
+                                  float* const* cvec, void* stream) {
   clear_error();
+  const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
   if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
   if (M <= 0 || B <= 0 || B % 128 != 0) return fail(HECKA_EINVAL, "gram_center_multi: needs B %% 128 == 0 (B = %lld)%s", "", B);
@@ -1209,7 +1302,7 @@ int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const
   long long wg = 0;
   for (int i = 0; i < L; ++i) {
     if (!X[i] || !sbar[i] || !C[i] || !cvec[i]) return fail(HECKA_EINVAL, "gram_center_multi: null layer pointer%s");
-    if (P[i] <= 0 || P[i] % 16 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * 4 >= (1ll << 32))
+    if (P[i] <= 0 || P[i] % 16 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * es >= (1ll << 32))
       return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)%s", "", P[i]);
     if (i > 0 && P[i] > P[i - 1]) return fail(HECKA_EINVAL, "gram_center_multi: layers must come deepest (largest P) first%s");
     have_max = have_max && xmax[i] != nullptr;
@@ -1220,7 +1313,14 @@ int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const
   if (wg > 0x7fffffffLL) return fail(HECKA_EINVAL, "gram_center_multi: grid too large%s");
   hipStream_t st = (hipStream_t)stream;
   const int xcd = (int)(M % 8 == 0);
-  if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
+  if (dtype != HECKA_DT_F32) {
+    if (!have_max || g_gemm_mode != HECKA_GEMM_AUTO)
+      return fail(HECKA_EINVAL, "gram_center_multi_x16: 16-bit features need xmax and HECKA_GEMM_AUTO%s");
+    if (dtype == HECKA_DT_BF16)
+      hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemBF16>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+    else
+      hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF16>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+  } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
   else
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
@@ -1630,6 +1730,35 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
   else
     hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   return check_launch("gram_bwd");
+}
+
+int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, int M, int B, int P,
+                       void* dX, void* stream) {
+  if (dtype == HECKA_DT_F32)
+    return hecka_gram_bwd_f32(W, static_cast<const float*>(X), wmax, xmax, M, B, P, static_cast<float*>(dX), stream);
+  clear_error();
+  if (dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) return fail(HECKA_EINVAL, "gram_bwd_x16: unknown dtype%s");
+  if (!W || !X || !dX || !wmax || !xmax) return fail(HECKA_EINVAL, "gram_bwd_x16: null pointer (wmax and xmax are required)%s");
+  if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_bwd_x16: bad size%s");
+  const int tilesM = B / 128, tilesN = P / 128;
+  const long long nwg = (long long)tilesM * tilesN * M;
+  if (g_gemm_mode != HECKA_GEMM_AUTO || B % 128 != 0 || P % 128 != 0 || !aligned16(W) || !aligned16(X) || !aligned16(dX) ||
+      nwg >= (1ll << 31) || (long long)B * P >= (1ll << 29) || (long long)B * B >= (1ll << 29))
+    return fail(HECKA_EINVAL, "gram_bwd_x16: needs HECKA_GEMM_AUTO, B %% 128 == 0, P %% 128 == 0, 16-byte alignment%s");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned* wm = reinterpret_cast<const unsigned*>(wmax);
+  const int xcd = (int)(M % 8 == 0);
+  const bool nofold = B <= 1024 && !getenv("HECKA_BWD_FOLD");
+#define HECKA_BWD16(FOLD, E) \
+  hipLaunchKernelGGL((gram_bwd_x6_kernel<1, FOLD, E>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, \
+                     tilesM, tilesN, xcd)
+  if (dtype == HECKA_DT_BF16) {
+    if (nofold) HECKA_BWD16(false, kElemBF16); else HECKA_BWD16(true, kElemBF16);
+  } else {
+    if (nofold) HECKA_BWD16(false, kElemF16); else HECKA_BWD16(true, kElemF16);
+  }
+#undef HECKA_BWD16
+  return check_launch("gram_bwd_x16");
 }
 
 }  // extern "C"

@@ -302,7 +302,7 @@ class ModelLayersKernel(BaseModelKernel):
             return None
         if not all(isinstance(k, _PairwiseHead) and k.shares_gram_launch() for k in kerns):
             return None
-        Xs = [ops._features_f32(FeatureKernel.flatten(f)) for f in flist]
+        Xs = [ops._features(FeatureKernel.flatten(f)) for f in flist]
         if not ops.multi_gram_eligible(Xs) or any(x.requires_grad and x.dtype != f.dtype for x, f in zip(Xs, flist)):
             return None
         with torch.no_grad():

@@ -31,9 +31,39 @@ def _features_f32(X):
     return X
 
 
-def _check_features(X):
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # HECKA_DT_* (include/hecka.h)
+
+
+def native16_eligible(Xs):
+    """bf16 / fp16 features that the x16 entry points read as they lie in HBM (no up-cast pass; dX comes back in the
+    feature type): GPU tensors of ONE 16-bit type with the same members and samples, B % 128 == 0, every P % 128 == 0,
+    split-precision GEMM mode.  HECKA_NATIVE16=0 forces the up-cast path."""
+    if not Xs or os.environ.get('HECKA_NATIVE16', '1') == '0':
+        return False
+    dt, M, B = Xs[0].dtype, Xs[0].shape[0], Xs[0].shape[1] if Xs[0].ndim == 3 else 0
+    if dt not in (torch.bfloat16, torch.float16) or B % 128 or B == 0:
+        return False
+    for X in Xs:
+        if not (X.is_cuda and X.dtype == dt and X.ndim == 3 and X.shape[0] == M and X.shape[1] == B):
+            return False
+        if X.shape[2] % 128 or X.shape[2] == 0 or B * X.shape[2] * 2 >= 2 ** 32:
+            return False
+    return _lib.lib().hecka_get_gemm_mode() == 0
+
+
+def _features(X):
+    """Features for the fused linear-Gram path: 16-bit tensors stay as they are when the x16 kernels take them,
+    everything else goes through _features_f32."""
+    if X.dtype in (torch.bfloat16, torch.float16) and native16_eligible([X]):
+        return X
+    return _features_f32(X)
+
+
+def _check_features(X, allow16=False):
     if not X.is_cuda:
         raise RuntimeError('hyper_amd kernels need features on the GPU (got %s); there is no CPU path' % X.device)
+    if allow16 and X.dtype in (torch.bfloat16, torch.float16) and X.ndim == 3 and native16_eligible([X]):
+        return
     if X.dtype != torch.float32:
         raise RuntimeError('hyper_amd kernels compute in fp32 (got %s)' % X.dtype)
     if X.ndim != 3:
@@ -72,6 +102,11 @@ def centered_gram(X, return_xmax=False):
     `return_xmax` adds xmax [M] = max |X[m]| (a by-product of the column-mean pass) for gram_backward: with it the
     dX GEMM may use the fp16-split arithmetic (include/hecka.h, HECKA_GEMM_AUTO)."""
     L = _lib.lib()
+    if X.dtype != torch.float32:      # 16-bit features: the multi-layer entry point with one layer
+        if not native16_eligible([X]):
+            raise RuntimeError('16-bit features of shape %s need the up-cast path (ops._features_f32)' % (tuple(X.shape),))
+        C, cvec, xmax = centered_gram_multi([X])[0]
+        return (C, cvec, xmax) if return_xmax else (C, cvec)
     M, B, P = X.shape
     sbar = torch.empty((M, P), device=X.device, dtype=torch.float32)
     xmax = torch.empty((M,), device=X.device, dtype=torch.float32)
@@ -87,9 +122,12 @@ def centered_gram(X, return_xmax=False):
 
 def multi_gram_eligible(Xs):
     """All layers can share ONE centred-Gram launch (hecka_gram_center_multi_f32): fp32 GPU features with the same
-    members and samples, B % 128 == 0, every P % 16 == 0, at most 16 layers, split-precision GEMM mode."""
+    members and samples, B % 128 == 0, every P % 16 == 0, at most 16 layers, split-precision GEMM mode; or 16-bit
+    features that native16_eligible accepts."""
     if not 2 <= len(Xs) <= 16:
         return False
+    if Xs[0].dtype in (torch.bfloat16, torch.float16):
+        return native16_eligible(Xs)
     M, B = Xs[0].shape[0], Xs[0].shape[1]
     for X in Xs:
         if not (X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.shape[0] == M and X.shape[1] == B):
@@ -109,6 +147,9 @@ def centered_gram_multi(Xs):
     dev = Xs[0].device
     order = sorted(range(len(Xs)), key=lambda i: -Xs[i].shape[2])
     Xs = [X.contiguous() for X in Xs]
+    dt = _DTYPE_CODE[Xs[0].dtype]
+    if any(X.dtype != Xs[0].dtype for X in Xs):
+        raise RuntimeError('centered_gram_multi: all layers need one feature dtype')
     out = []
     for X in Xs:
         P = X.shape[2]
@@ -116,12 +157,12 @@ def centered_gram_multi(Xs):
         xmax = torch.empty((M,), device=dev, dtype=torch.float32)
         C = torch.empty((M, B, B), device=dev, dtype=torch.float32)
         cvec = torch.empty((M, B), device=dev, dtype=torch.float32)
-        _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
+        _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
         out.append((C, cvec, xmax, sbar))
     n = len(Xs)
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
-    _lib.check(L.hecka_gram_center_multi_f32(
-        n, ptrs([Xs[i] for i in order]), ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
+    _lib.check(L.hecka_gram_center_multi_x16(
+        n, ptrs([Xs[i] for i in order]), dt, ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
         (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]), ptrs([out[i][0] for i in order]),
         ptrs([out[i][1] for i in order]), st), 'gram_center_multi')
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
@@ -204,7 +245,7 @@ def gram_bwd_w(W, X, wmax=None, xmax=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().hecka_gram_bwd_f32(_p(W), _p(X), _p(wmax) if wmax is not None else None,
+    _lib.check(_lib.lib().hecka_gram_bwd_x16(_p(W), _p(X), _DTYPE_CODE[X.dtype], _p(wmax) if wmax is not None else None,
                                              _p(xmax) if xmax is not None else None, Ma, B, P, _p(dX), _stream()),
                'gram_bwd')
     if PROFILE is not None:
@@ -432,7 +473,7 @@ class DiversityLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, spec, detach_diag, reduce, gspec, pre=None):
-        _check_features(X)
+        _check_features(X, allow16=gspec is None or gspec.kind == GRAM_LINEAR)
         X = X.contiguous()
         L = _lib.lib()
         M = X.shape[0]
@@ -481,7 +522,8 @@ class DiversityLayer(torch.autograd.Function):
 
 
 def diversity_layer(X, spec, detach_diag=True, reduce=None, gspec=None, pre=None):
-    return DiversityLayer.apply(_features_f32(X), spec, detach_diag, reduce, gspec, pre)
+    linear = gspec is None or gspec.kind == GRAM_LINEAR
+    return DiversityLayer.apply(_features(X) if linear else _features_f32(X), spec, detach_diag, reduce, gspec, pre)
 
 
 _OFFDIAG_INDEX = {}

@@ -237,6 +237,10 @@ def sharded_layers_loss(feats, specs, weights, detach_diag=True, reduce='mean', 
         from . import ops as backend
     if reduce not in ('mean', 'sum'):
         raise ValueError("the sharded loss supports reduction 'mean' or 'sum'")
+    if hasattr(backend, '_features'):      # 16-bit features: native where the kernels take them, else the exact up-cast
+        feats = [backend._features(X) for X in feats]
+        if len({X.dtype for X in feats}) > 1:
+            feats = [backend._features_f32(X) for X in feats]
     fn = _SlicedLayers if shard_mode(backend) == 'slice' else _GatheredLayers
     return fn.apply((backend, group, list(specs), list(weights), bool(detach_diag), reduce), *feats)
 

@@ -204,6 +204,24 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
                             const float* weight, int G, int N, int C, long long S, int training, float* dx,
                             float* dweight, float* dbias, void* stream);
 
+/* ---- 16-bit features (BASELINE config 3: bf16 networks) ------------------------------------------------------------
+ * The reference runs the same Python path on bf16 feature tensors (torch.bmm in bf16, hyper/diversity/kernels.py:122);
+ * here the three kernels that touch X read bf16 / fp16 features as they lie in HBM (half the bytes, no up-cast pass),
+ * widen them to fp32 in registers and compute exactly as the fp32 entry points do; C, cvec, S, W stay fp32.
+ * dtype: HECKA_DT_F32 forwards to the fp32 entry point.  Interior shapes only (B % 128 == 0; P % 16 == 0 for the Gram,
+ * P % 128 == 0 for dX), HECKA_GEMM_AUTO, xmax / wmax required - otherwise HECKA_EINVAL: up-cast and use the fp32 calls.
+ * hecka_gram_bwd_x16: 16-bit X times the power-of-two scale is exact in ONE fp16 term, so the product list is
+ * W.h X + W.l X (two MFMA products per multiply); dX is written in the feature type (rounded once, to nearest). */
+#define HECKA_DT_F32 0
+#define HECKA_DT_BF16 1
+#define HECKA_DT_F16 2
+int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar, float* xmax, void* stream);
+int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
+                                const float* const* xmax, int M, int B, const int* P, float* const* C,
+                                float* const* cvec, void* stream);
+int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, int M, int B,
+                       int P, void* dX, void* stream);
+
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
  * hecka_colmean_f32, or upper bounds of them (hecka_wbound_f32); both given enables f16x3 (see HECKA_GEMM_AUTO). */
