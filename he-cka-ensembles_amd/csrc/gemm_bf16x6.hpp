@@ -116,10 +116,11 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
 // only for short K - the 16-bit MFMA's truncation bias grows with the chain (about -5e-10 of sum|a.b| per k).
 // EA / EB: element kinds of the operands in HBM.  BLOW = false (f16x3 only): the staged B values are exact in ONE fp16
 // term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
+// ALOW = false: the same for A (both false: one product, hh).
 template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
-          bool BLOW = true>
+          bool BLOW = true, bool ALOW = true>
 struct GemmTileX6 {
-  static_assert(BLOW || SCHEME == 1, "single-plane B operand: f16x3 only");
+  static_assert((BLOW && ALOW) || SCHEME == 1, "single-plane operands: f16x3 only");
   static constexpr int SA = elem_bytes<EA>(), SB = elem_bytes<EB>();
   static constexpr int NP = SCHEME == 1 ? 2 : 3;
   static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
@@ -221,7 +222,7 @@ struct GemmTileX6 {
           split2(ra[S][i], 2, p[0], p[1], p[2], 1);
         }
 #pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
+        for (int q = 0; q < (ALOW ? NP : 1); ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
       }
     };
     auto stage_b = [&](auto SET, int st) __attribute__((always_inline)) {
@@ -338,9 +339,11 @@ struct GemmTileX6 {
       f16x8 fa[MI][2], fb[NI][2];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
+        if (p == 0 || ALOW) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+          for (int i = 0; i < MI; ++i)
+            fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+        }
         if (p == 0 || BLOW) {
 #pragma unroll
           for (int j = 0; j < NI; ++j)
@@ -354,7 +357,7 @@ struct GemmTileX6 {
 #pragma unroll
       for (int n = 0; n < 12; ++n) {
         const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        if (BLOW || e != 1) {   // e = 1 is A.h x B.l
+        if (e == 0 || (e == 1 && BLOW) || (e == 2 && ALOW)) {   // e = 1 is A.h x B.l, e = 2 is A.l x B.h
           if (FOLD) {
             f32x16 c = loc[i][j];
             if (decltype(FIRST)::value && e == 0) {
@@ -382,7 +385,7 @@ struct GemmTileX6 {
             } else {
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q];
+                if (isA) { if (q == 0 || ALOW) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q]; }
                 else if (q == 0 || BLOW) *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
               }
             }

@@ -267,6 +267,91 @@ struct CenterProX6 {
   template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
 
+// RAW (16-bit features only): the MFMA operand is the feature itself - exact in one fp16 term, ONE product per multiply,
+// products exact - and the centring moves to the epilogue: C[a,b] = K[a,b] - u_a with u_a = x_a . sbar = c_a + |sbar|^2
+// (c_a is still accumulated from the centred values in fp32).  K - u cancels where the centred product does not, by the
+// ratio |sbar|^2 / var: fp32 absolute error 2^-24 |K|, far inside the 1e-2 budget of 16-bit features, outside the 1e-5
+// of fp32 ones - hence 16-bit only, HECKA_X16_EXACT=1 selects the centred three-product form.
+template <int SCHEME>
+struct RawProX6 {
+  const float* sbar;
+  float s;
+  f32x4 s4[2];
+  f32x4 cav[2], cbv[2];
+  f32x4 ssv;              // partial |sbar|^2 over the k this thread stages
+  template <class S> __device__ __forceinline__ void prefetch(S, int k) {
+    s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
+  }
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int i) {
+    const f32x4 m4 = s4[S::value];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cav[i][e] = fmaf(v[e] - m4[e], m4[e], cav[i][e]);
+      if (i == 0) ssv[e] = fmaf(m4[e], m4[e], ssv[e]);
+      v[e] *= s;
+    }
+  }
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int i) {
+    const f32x4 m4 = s4[S::value];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cbv[i][e] = fmaf(v[e] - m4[e], m4[e], cbv[i][e]);
+      v[e] *= s;
+    }
+  }
+};
+
+template <int EX>
+__device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
+                                                 const float* __restrict__ xmax, float* __restrict__ C,
+                                                 float* __restrict__ cvec, int B, int P, int ntile, int xcd_map, int w) {
+  static_assert(EX != kElemF32, "raw Gram: 16-bit features only");
+  using Tile = GemmTileX6<128, 128, false, RawProX6<1>, 1, true, EX, EX, false, false>;
+  __shared__ typename Tile::Smem sm;
+  __shared__ float cA[128], cB[128], ssum;
+  int m, rem;
+  member_tile_w(w, ntile * (ntile + 1) / 2, xcd_map, m, rem);
+  int I = 0;
+  while (rem >= ntile - I) {
+    rem -= ntile - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * 2u;
+  RawProX6<1> pro;
+  pro.sbar = sbar + (size_t)m * P;
+  pro.s = pow2_scale(xmax[m], 14);
+  pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = pro.ssv = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float unscale = 1.0f / (pro.s * pro.s);
+  Tile tile;
+  tile.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+  float ss = pro.ssv[0] + pro.ssv[1] + pro.ssv[2] + pro.ssv[3];
+  ss += __shfl_xor(ss, 1);
+  ss += __shfl_xor(ss, 2);
+  if (threadIdx.x == 0) ssum = ss;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = pro.cav[i][0] + pro.cav[i][1] + pro.cav[i][2] + pro.cav[i][3];
+    float b = pro.cbv[i][0] + pro.cbv[i][1] + pro.cbv[i][2] + pro.cbv[i][3];
+    a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+    a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+    if ((threadIdx.x & 3) == 0) {
+      cA[(threadIdx.x >> 2) + 64 * i] = a;
+      cB[(threadIdx.x >> 2) + 64 * i] = b;
+    }
+  }
+  __syncthreads();
+  float* Cm = C + (size_t)m * B * B;
+  const int row0 = I * 128, col0 = J * 128;
+  const float s2 = ssum;
+  if (I == J && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
+  tile.for_each([&](int lr, int lc, float v) {
+    v *= unscale;
+    Cm[(size_t)(row0 + lr) * B + col0 + lc] = v - (cA[lr] + s2);
+    if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v - (cB[lc] + s2);
+  });
+}
+
 template <int SCHEME, int EX = kElemF32>
 __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
@@ -342,7 +427,7 @@ struct GramMultiArgs {
   int L;
 };
 
-template <int SCHEME, int EX = kElemF32>
+template <int SCHEME, int EX = kElemF32, bool RAW = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
   const int w = blockIdx.x;
   int li = 0, w0 = 0;
@@ -356,7 +441,8 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
 #pragma unroll
   for (int i = 1; i < kMaxGramLayers; ++i)
     if (i == li) { X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P; }
-  gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
+  if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
+  else gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1316,10 +1402,15 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   if (dtype != HECKA_DT_F32) {
     if (!have_max || g_gemm_mode != HECKA_GEMM_AUTO)
       return fail(HECKA_EINVAL, "gram_center_multi_x16: 16-bit features need xmax and HECKA_GEMM_AUTO%s");
-    if (dtype == HECKA_DT_BF16)
-      hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemBF16>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
-    else
-      hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF16>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+    const bool raw = !getenv("HECKA_X16_EXACT");
+#define HECKA_GRAM16(E, R) \
+  hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, E, R>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd)
+    if (dtype == HECKA_DT_BF16) {
+      if (raw) HECKA_GRAM16(kElemBF16, true); else HECKA_GRAM16(kElemBF16, false);
+    } else {
+      if (raw) HECKA_GRAM16(kElemF16, true); else HECKA_GRAM16(kElemF16, false);
+    }
+#undef HECKA_GRAM16
   } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
   else

@@ -217,18 +217,25 @@ def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
         assert err <= RTOL, err
 
 
-@pytest.mark.parametrize('dtype,native', [('bfloat16', '1'), ('float16', '1'), ('bfloat16', '0')])
+@pytest.mark.parametrize('dtype,native', [('bfloat16', '1'), ('float16', '1'), ('bfloat16', '0'), ('bfloat16', 'exact')])
 @pytest.mark.parametrize('dims', [(256, 1024), (128,), (256, 80)])
 def test_16bit_features_match_oracle_on_rounded_values(dtype, native, dims, monkeypatch):
     """BASELINE config 3 / SURVEY.md 8d: bf16 (and fp16) features; oracle = the restatement in fp64 on the rounded
     values.  north_star tolerance for bf16 features: rel 1e-2; held here: the loss at the fp32 level (1e-5) and the
     gradient to its single rounding into the feature type (2^-8 bf16, 2^-11 fp16, of the largest gradient).
     native=1: the x16 entry points read the 16-bit features directly (dims that are not multiples of 128 fall back
-    to the up-cast); native=0: HECKA_NATIVE16=0, up-cast for everything."""
+    to the up-cast); native=0: HECKA_NATIVE16=0, up-cast for everything; exact: native with HECKA_X16_EXACT=1 (centred
+    three-product Gram instead of the raw one-product Gram, whose K - u cancellation costs the loss a digit)."""
     from oracle import hecka_ref as R
     from hyper_amd import ops
     from hyper_amd.diversity.model_kernels import build_model_kernel
     from collections import OrderedDict
+    raw = native == '1'
+    if native == 'exact':
+        monkeypatch.setenv('HECKA_X16_EXACT', '1')
+        native = '1'
+    else:
+        monkeypatch.delenv('HECKA_X16_EXACT', raising=False)
     monkeypatch.setenv('HECKA_NATIVE16', native)
     dev = _dev()
     dt = getattr(torch, dtype)
@@ -244,7 +251,7 @@ def test_16bit_features_match_oracle_on_rounded_values(dtype, native, dims, monk
     xo = [x.detach().double().requires_grad_(True) for x in xs]
     ref = R.run_config(cfg, xo)
     ref.backward()
-    assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert abs(out.item() - ref.item()) <= (1e-4 if raw else 1e-5) * abs(ref.item())
     for x, o in zip(xs, xo):
         assert x.grad.dtype == dt
         gmax = float(o.grad.abs().max())
@@ -254,9 +261,12 @@ def test_16bit_features_match_oracle_on_rounded_values(dtype, native, dims, monk
         assert err <= tol * 1.01, (err, tol)
 
 
-def test_native_16bit_equals_upcast_path(monkeypatch):
-    """The x16 kernels against the fp32 kernels on the up-cast copy of the same bf16 features: same loss to 1e-6 and
-    gradients that differ by at most one bf16 ulp (both round an fp32-accurate value once), bench member/sample counts."""
+@pytest.mark.parametrize('exact', [True, False])
+def test_native_16bit_equals_upcast_path(exact, monkeypatch):
+    """The x16 kernels against the fp32 kernels on the up-cast copy of the same bf16 features, bench member/sample
+    counts.  exact (HECKA_X16_EXACT=1): same loss to 1e-6 and gradients that differ by at most one bf16 ulp (both round
+    an fp32-accurate value once).  Default (raw one-product Gram): loss to 1e-4, gradients to one ulp + 1e-4 of the
+    largest."""
     from hyper_amd.diversity.model_kernels import build_model_kernel
     from collections import OrderedDict
     dev = _dev()
@@ -266,18 +276,23 @@ def test_native_16bit_equals_upcast_path(monkeypatch):
                                 feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
     base = [torch.randn(64, 512, p, device=dev).bfloat16() for p in (512, 1280)]
     res = {}
+    if exact:
+        monkeypatch.setenv('HECKA_X16_EXACT', '1')
+    else:
+        monkeypatch.delenv('HECKA_X16_EXACT', raising=False)
     for native in ('1', '0'):
         monkeypatch.setenv('HECKA_NATIVE16', native)
         xs = [x.clone().requires_grad_(True) for x in base]
         out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
         out.backward()
         res[native] = (out.item(), [x.grad for x in xs])
-    assert abs(res['1'][0] - res['0'][0]) <= 1e-6 * abs(res['0'][0])
+    assert abs(res['1'][0] - res['0'][0]) <= (1e-6 if exact else 1e-4) * abs(res['0'][0])
     for g1, g0 in zip(res['1'][1], res['0'][1]):
         d = (g1.float() - g0.float()).abs()
-        ulp = g0.float().abs() * 2.0 ** -7 + 1e-30
+        ulp = g0.float().abs() * 2.0 ** -7 + (1e-30 if exact else 1e-4 * float(g0.float().abs().max()))
         assert bool((d <= ulp).all())
-        assert float((d > 0).float().mean()) < 0.02      # the two roundings disagree only near a rounding boundary
+        if exact:
+            assert float((d > 0).float().mean()) < 0.02      # the two roundings disagree only near a rounding boundary
 
 
 def test_learnable_head_matches_autograd_oracle():

@@ -34,6 +34,7 @@ def timed(fn, steps, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--only', default='', help='one variant (and no library ceiling)')
     args = ap.parse_args()
     import bench
     from hyper_amd.diversity.model_kernels import build_model_kernel
@@ -64,6 +65,9 @@ def main():
         dt = timed(step, args.steps)
         print('%-11s %7.1f evals/s  %6.3f ms/eval  loss %.6f' % (name, 1.0 / dt, 1e3 * dt, out['loss'].item()), flush=True)
 
+    if args.only:
+        variant(args.only)
+        return
     for name in ('base', 'correlated', 'he_exp', 'bf16'):
         variant(name)
 
