@@ -148,7 +148,7 @@ def main():
         if mode == 0:
             # interior shapes, maxima supplied: every fp32 multiply is THREE fp16 MFMA products (gemm_bf16x6.hpp,
             # scheme f16x3), so the MFMA roof for ALGORITHMIC fp32 flops is the dense 16-bit peak / 3
-            kname = 'gram_bwd_x6_kernel<1, false> (dX = W X; fp32 operands split into 2 fp16 terms, 3 fp16 MFMA products per multiply)'
+            kname = 'gram_bwd_x6_kernel<1, false, 0> (dX = W X; fp32 operands split into 2 fp16 terms, 3 fp16 MFMA products per multiply)'
             peak, hw = PEAK_BF16_MATRIX_TFLOPS / 3.0, {'hw_f16_tflops': ach * 3.0, 'hw_f16_peak': PEAK_BF16_MATRIX_TFLOPS}
         elif mode == 2:
             kname = 'gram_bwd_x6_kernel<0> (dX = W X; fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply)'
@@ -161,7 +161,7 @@ def main():
         tfile = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
         if world == 1 and mode == 0 and os.path.exists(tfile):
             with open(tfile) as fh:
-                traffic = json.load(fh)['kernels']['gram_bwd_x6_kernel<1, false>']['hbm_bytes']
+                traffic = json.load(fh)['kernels']['gram_bwd_x6_kernel<1, false, 0>']['hbm_bytes']
         flops_eval = sum(4.0 * M * B * B * p + 4.0 * M * M * B * B for p in DIMS)
         out = {
             'metric': 'HE-CKA loss+grad evals/sec (M=64, B=512, 5 layers)', 'value': args.steps / dt, 'unit': 'evals/s',
