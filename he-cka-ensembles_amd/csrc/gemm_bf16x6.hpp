@@ -118,8 +118,11 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
 // term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
 // ALOW = false: the same for A (both false: one product, hh).
 template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
-          bool BLOW = true, bool ALOW = true>
+          bool BLOW = true, bool ALOW = true, bool SAMEAB = false>
 struct GemmTileX6 {
+  // SAMEAB (NT, diagonal tile of a symmetric product): the B rows ARE the A rows - nothing is loaded, split or staged
+  // for B, its fragments come from the A planes
+  static_assert(!SAMEAB || (!NN && TM == TN), "SAMEAB: NT product with a square tile");
   static_assert((BLOW && ALOW) || SCHEME == 1, "single-plane operands: f16x3 only");
   static constexpr int SA = elem_bytes<EA>(), SB = elem_bytes<EB>();
   static constexpr int NP = SCHEME == 1 ? 2 : 3;
@@ -179,6 +182,7 @@ struct GemmTileX6 {
     auto gload_b = [&](auto SET, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(SET)::value;
       pro.prefetch(SET, kbeg + kt * kX6BK + 4 * kq);
+      if (SAMEAB) return;
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         if (NN) {
@@ -227,6 +231,7 @@ struct GemmTileX6 {
     };
     auto stage_b = [&](auto SET, int st) __attribute__((always_inline)) {
       constexpr int S = decltype(SET)::value;
+      if (SAMEAB) return;
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         u32x2 p[3];
@@ -279,7 +284,7 @@ struct GemmTileX6 {
       auto ldb_ = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          fb[j][p] = *reinterpret_cast<const bf16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(&(SAMEAB ? sm.a : sm.b)[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
       };
       lda_(2);
       ldb_(0);
@@ -308,7 +313,7 @@ struct GemmTileX6 {
           const bool isA = n < 8;
           const int quad = (n >> 2) & 1, step = (n & 3) - 1;
           f32x4& src = isA ? ra[S][quad] : rb[S][quad];
-          if (more) {
+          if (more && (isA || !SAMEAB)) {
             if (step == 0) {
               if (isA) { widen_quad<EA, false>(src); pro.stageA(NSET, src, quad); }
               else { widen_quad<EB, NN>(src); pro.stageB(NSET, src, quad); }
@@ -347,7 +352,7 @@ struct GemmTileX6 {
         if (p == 0 || BLOW) {
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            fb[j][p] = *reinterpret_cast<const f16x8*>(&sm.b[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+            fb[j][p] = *reinterpret_cast<const f16x8*>(&(SAMEAB ? sm.a : sm.b)[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -376,7 +381,7 @@ struct GemmTileX6 {
           const bool isA = n < 4;
           const int r = isA ? n : n - 5, quad = r >> 1, step = r & 1;
           f32x4& src = isA ? ra[S][quad] : rb[S][quad];
-          if (more) {
+          if (more && (isA || !SAMEAB)) {
             if (step == 0) {
               if (isA) { widen_quad<EA, false>(src); pro.stageA(NSET, src, quad); }
               else { widen_quad<EB, NN>(src); pro.stageB(NSET, src, quad); }

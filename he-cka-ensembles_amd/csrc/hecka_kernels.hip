@@ -307,6 +307,7 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
                                                  float* __restrict__ cvec, int B, int P, int ntile, int xcd_map, int w) {
   static_assert(EX != kElemF32, "raw Gram: 16-bit features only");
   using Tile = GemmTileX6<128, 128, false, RawProX6<1>, 1, true, EX, EX, false, false>;
+  using TileD = GemmTileX6<128, 128, false, RawProX6<1>, 1, true, EX, EX, false, false, true>;   // diagonal tiles
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128], ssum;
   int m, rem;
@@ -324,7 +325,18 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = pro.ssv = f32x4{0.f, 0.f, 0.f, 0.f};
   const float unscale = 1.0f / (pro.s * pro.s);
   Tile tile;
-  tile.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+  if (I == J) {
+    TileD td;
+    td.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tile.acc[i][j] = td.acc[i][j];
+    pro.cbv[0] = pro.cav[0];
+    pro.cbv[1] = pro.cav[1];
+  } else {
+    tile.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+  }
   float ss = pro.ssv[0] + pro.ssv[1] + pro.ssv[2] + pro.ssv[3];
   ss += __shfl_xor(ss, 1);
   ss += __shfl_xor(ss, 2);
@@ -358,6 +370,7 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
                                                     int w) {
   using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX>;
+  using TileD = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX, true, true, true>;   // diagonal tiles
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
@@ -376,7 +389,18 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float unscale = SCHEME == 1 ? 1.0f / (pro.s * pro.s) : 1.0f;
   Tile tile;
-  tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
+  if (I == J) {
+    TileD td;
+    td.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tile.acc[i][j] = td.acc[i][j];
+    pro.cbv[0] = pro.cav[0];
+    pro.cbv[1] = pro.cav[1];
+  } else {
+    tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
+  }
   // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
