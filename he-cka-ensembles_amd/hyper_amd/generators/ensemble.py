@@ -159,7 +159,14 @@ class FixedEnsembleModel(nn.Module):
         if size is None:
             return torch.arange(0, self.size, device=device, dtype=torch.long)
         if isinstance(size, (list, set)):
-            return torch.tensor(list(size), device=device, dtype=torch.long)
+            # an explicit member list: the index tensor is kept (no host-to-device copy per step; graph capture needs that)
+            key = (tuple(size), str(device))
+            cache = self.__dict__.setdefault('_member_id_cache', {})
+            if key not in cache:
+                if len(cache) > 64:
+                    cache.clear()
+                cache[key] = torch.tensor(list(size), device=device, dtype=torch.long)
+            return cache[key]
         return torch.randperm(self.size, device=device, dtype=torch.long)[:size]
 
     def forward_params(self, codes, device=None):
@@ -173,8 +180,16 @@ class FixedEnsembleModel(nn.Module):
         elif codes is None:
             codes = torch.arange(0, self.size, device=device, dtype=torch.long)
         assert codes.ndim <= 1, 'Invalid number of code dims. Expecting 1'
-        if torch.any(codes < 0) or torch.any(codes >= self.size):
-            raise ValueError('Invalid model index in codes. Please only select members from indices 0 to %d' % self.size)
+        # the range check reads the ids back to the host: once per id tensor, not once per step (the tensors that
+        # sample_params keeps for explicit member lists come back here every step; a capture cannot synchronise)
+        checked = self.__dict__.setdefault('_checked_codes', {})
+        key = (codes.data_ptr(), codes.numel(), codes._version)
+        if checked.get(key) is not codes:
+            if torch.any(codes < 0) or torch.any(codes >= self.size):
+                raise ValueError('Invalid model index in codes. Please only select members from indices 0 to %d' % self.size)
+            cached = self.__dict__.get('_member_id_cache', {})
+            if any(codes is t for t in cached.values()):
+                checked[key] = codes
         idx = codes.reshape(-1).long()
         params = DefaultOrderedDict()
         for names, gen in self._iter([], self.layer_generators):

@@ -670,3 +670,48 @@ def test_cossim_zero_row_is_nan_and_the_method_masks_it():
     track = method(types.SimpleNamespace(training=True), OrderedDict(), [], track, None, torch.randint(0, 3, (6,), device=dev), step=5)
     assert torch.isnan(track['ind_rep_loss']) and torch.isfinite(track['loss'])
     assert abs(track['loss'].item() - track['ind_loss'].item()) < 1e-6
+
+
+def test_graphed_train_step_equals_eager():
+    """hyper_amd.experiments.graphed.GraphedTrainStep: three eager steps + two graph replays must leave the same
+    weights as five eager steps (LeNet-5 ensemble, HE repulsion, AdamW)."""
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from hyper_amd.experiments.graphed import GraphedTrainStep
+    dev = _dev()
+    M, B = 4, 64
+    hcfg = {'name': 'ensemble', 'ensemble_size': M, 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}}
+    mcfg = {'name': 'repulsive_kernel', 'num': M, 'gamma': 10.5, 'warmup': 0, 'ind_loss': {'name': 'cross_entropy'},
+            'model_kernel': {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+                             'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031,
+                                              'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}}}}
+    torch.manual_seed(0)
+    X = torch.randn(B, 1, 28, 28, device=dev)
+    Y = torch.randint(0, 10, (B,), device=dev)
+    trainer = types.SimpleNamespace(training=True)
+    finals = []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        hyper = build_generator(hcfg).to(dev)
+        method = build_method(mcfg).to(dev)
+        params = list(hyper.parameters()) + list(method.parameters())
+        opt = torch.optim.AdamW(params, lr=1e-3, capturable=True)
+        if graphed:
+            g = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=list(range(M)), step=1000, warmup_iters=3)
+            for _ in range(2):
+                loss = g(X, Y)
+        else:
+            for _ in range(5):
+                opt.zero_grad(set_to_none=True)
+                track = hyper(params=list(range(M)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+                track = method(trainer, track['params'], [], track, X, Y, step=1000)
+                track['loss'].backward()
+                opt.step()
+                loss = track['loss']
+        torch.cuda.synchronize()
+        finals.append((float(loss.detach()), [p.detach().clone() for p in hyper.parameters()]))
+    assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * abs(finals[0][0])
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-12)

@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--graph', action='store_true', help='capture the step in one HIP graph (hyper_amd.experiments.graphed)')
     args = ap.parse_args()
     c = configs(args.members)[args.config]
     M, B = c['members'], args.batch or c['batch']
@@ -83,7 +84,8 @@ def main():
     hyper = build_generator(c['hyper']).to(dev)
     method = build_method(c['method']).to(dev)
     params = list(hyper.parameters()) + list(method.parameters())
-    opt = (torch.optim.AdamW(params, lr=1e-3) if c['opt'] == 'adamw' else torch.optim.SGD(params, lr=0.01, momentum=0.9))
+    opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph) if c['opt'] == 'adamw'
+           else torch.optim.SGD(params, lr=0.01, momentum=0.9))
     X = torch.randn(B, *c['x'], device=dev)
     Y = torch.randint(0, c['classes'], (B,), device=dev)
     trainer = types.SimpleNamespace(training=True)
@@ -96,6 +98,10 @@ def main():
         opt.step()
         return track['loss']
 
+    if args.graph:
+        from hyper_amd.experiments.graphed import GraphedTrainStep
+        graphed = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=list(range(M)), step=1000)
+        step = lambda i: graphed()   # noqa: E731
     sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
     for i in range(args.warmup):
         loss = step(i)
@@ -106,7 +112,7 @@ def main():
     sync()
     dt = (time.perf_counter() - t0) / args.steps
     print('%s impl=%s M=%d B=%d: %.2f ms/step  %.1f steps/s  loss %.4f%s' % (
-        args.config, args.impl, M, B, dt * 1e3, 1.0 / dt, float(loss),
+        args.config, args.impl + ('+graph' if args.graph else ''), M, B, dt * 1e3, 1.0 / dt, float(loss),
         '  (%d CPU threads)' % torch.get_num_threads() if args.impl == 'ref' else ''))
 
 
