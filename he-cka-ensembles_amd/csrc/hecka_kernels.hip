@@ -606,6 +606,9 @@ __global__ void coef_gamma_kernel(const float* __restrict__ A, const float* __re
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
   if (b >= B) return;
+  A += (size_t)blockIdx.z * Ma * Mb;        // blockIdx.z: layer of a batched call ([L,Ma,Mb] x [L,Mb,B] -> [L,Ma,B])
+  cvec += (size_t)blockIdx.z * Mb * B;
+  gamma += (size_t)blockIdx.z * Ma * B;
   float s = 0.f;
 #pragma unroll 8
   for (int j = 0; j < Mb; ++j) s += A[(size_t)i * Mb + j] * cvec[(size_t)j * B + b];
@@ -755,6 +758,10 @@ __global__ __launch_bounds__(256) void wbound_kernel(const float* __restrict__ A
                                                      float* __restrict__ wbound) {
   __shared__ float red[4];
   const int i = blockIdx.x;
+  A += (size_t)blockIdx.y * gridDim.x * Mb;        // blockIdx.y: layer of a batched call
+  nsq += (size_t)blockIdx.y * Mb;
+  gamma += (size_t)blockIdx.y * gridDim.x * B;
+  wbound += (size_t)blockIdx.y * gridDim.x;
   float s = 0.f, g = 0.f;
   for (int jj = threadIdx.x; jj < Mb; jj += 256) s += fabsf(A[(size_t)i * Mb + jj]) * sqrtf(fmaxf(nsq[jj], 0.f));
   for (int b = threadIdx.x; b < B; b += 256) g = fmaxf(g, fabsf(gamma[(size_t)i * B + b]));
@@ -969,9 +976,9 @@ __device__ __forceinline__ double block_sum_head(double v, double* red) {
 
 // forward: one workgroup (the sum over all pairs is taken in a fixed order: deterministic)
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
-                                                           int Ma, int Mb, HeadCfg c, float* __restrict__ val,
-                                                           float* __restrict__ sum_out, double scale) {
+__device__ __forceinline__ void head_fwd_body(const float* __restrict__ S, const float* __restrict__ nsq, int Ma, int Mb,
+                                              const HeadCfg& c, float* __restrict__ val, float* __restrict__ sum_out,
+                                              double scale) {
   __shared__ double red[THREADS / 64];
   double acc = 0.0;
   for (int e = threadIdx.x; e < Ma * Mb; e += THREADS) {
@@ -993,15 +1000,47 @@ __global__ __launch_bounds__(THREADS) void head_fwd_kernel(const float* __restri
   }
 }
 
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void head_fwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                           int Ma, int Mb, HeadCfg c, float* __restrict__ val,
+                                                           float* __restrict__ sum_out, double scale) {
+  head_fwd_body<THREADS>(S, nsq, Ma, Mb, c, val, sum_out, scale);
+}
+
+// Every tracked layer's head in ONE launch (workgroup = layer): five launches of a 64 x 64 problem cost more than the
+// problem.  The per-layer settings travel in the kernel arguments and are selected with scalar compares.
+struct HeadBatch {
+  HeadCfg c[kMaxGramLayers];
+  double scale[kMaxGramLayers];
+};
+__device__ __forceinline__ void head_select(const HeadBatch& hb, int l, HeadCfg& c, double& scale) {
+  c = hb.c[0];
+  scale = hb.scale[0];
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == l) {
+      c = hb.c[i];
+      scale = hb.scale[i];
+    }
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void head_fwd_batched_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                                   int Ma, int Mb, HeadBatch hb, float* __restrict__ totals) {
+  const int l = blockIdx.x;
+  HeadCfg c;
+  double scale;
+  head_select(hb, l, c, scale);
+  head_fwd_body<THREADS>(S + (size_t)l * Ma * Mb, nsq + (size_t)l * Mb, Ma, Mb, c, nullptr, totals + l, scale);
+}
+
 // backward: rows are independent - one wave per row i, four rows per workgroup, no LDS.
 // upstream dLoss/dvalue_ij = (up_mat ? up_mat[i,j] : 1) * (up_scalar ? *up_scalar : 1) * scale.
 // A matrix upstream needs the transposed entry too, so it requires Ma == Mb (single GPU).
 //   Gs_ij = G_ij (+ G_ji)   (cos is symmetric, so G_ji differs from G_ij only through up_mat)
 //   A_ij = Gs_ij/(d_i d_j);  A_ii = Gs_ii eps/d_i^3 - (sum_{j!=i} Gs_ij S_ij/d_j)/(n_i d_i^2)
-__global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
-                                                       int Ma, int Mb, HeadCfg c, const float* __restrict__ up_mat,
-                                                       const float* __restrict__ up_scalar, double scale,
-                                                       float* __restrict__ A) {
+__device__ __forceinline__ void head_bwd_body(const float* __restrict__ S, const float* __restrict__ nsq, int Ma, int Mb,
+                                              const HeadCfg& c, const float* __restrict__ up_mat,
+                                              const float* __restrict__ up_scalar, double scale, float* __restrict__ A) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * (kHeadThreads / 64) + wave;
   if (i >= Ma) return;
@@ -1036,6 +1075,24 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __r
     const double self = ni > 0.0 ? vg / (ni * di * di) : 0.0;
     A[(size_t)i * Mb + gi] = (float)(gii * c.eps / (di * di * di) - self);
   }
+}
+
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(const float* __restrict__ S, const float* __restrict__ nsq,
+                                                       int Ma, int Mb, HeadCfg c, const float* __restrict__ up_mat,
+                                                       const float* __restrict__ up_scalar, double scale,
+                                                       float* __restrict__ A) {
+  head_bwd_body(S, nsq, Ma, Mb, c, up_mat, up_scalar, scale, A);
+}
+
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_batched_kernel(const float* __restrict__ S,
+                                                                        const float* __restrict__ nsq, int Ma, int Mb,
+                                                                        HeadBatch hb, const float* __restrict__ up_scalar,
+                                                                        float* __restrict__ A) {
+  const int l = blockIdx.y;
+  HeadCfg c;
+  double scale;
+  head_select(hb, l, c, scale);
+  head_bwd_body(S + (size_t)l * Ma * Mb, nsq + (size_t)l * Mb, Ma, Mb, c, nullptr, up_scalar, scale, A + (size_t)l * Ma * Mb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1719,6 +1776,67 @@ int hecka_head_bwd_f32(const float* S, const float* nsq, int Ma, int Mb, int row
   hipLaunchKernelGGL(head_bwd_kernel, dim3((Ma + kHeadThreads / 64 - 1) / (kHeadThreads / 64)), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma, Mb, c, up_mat, up_scalar,
                      scale, A);
   return check_launch("head_bwd");
+}
+
+static int head_batch(HeadBatch& hb, int L, int Ma, int Mb, int row_offset, const int* kind, const double* s,
+                      const double* eps, const double* arc_eps, const int* flags, const double* scale) {
+  if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "head (batched): 1..16 layers%s");
+  if (!kind || !s || !eps || !arc_eps || !flags || !scale) return fail(HECKA_EINVAL, "head (batched): null settings%s");
+  for (int l = 0; l < L; ++l) {
+    if (int rc = head_cfg(hb.c[l], kind[l], s[l], eps[l], arc_eps[l], flags[l], row_offset, Ma, Mb)) return rc;
+    hb.scale[l] = scale[l];
+  }
+  for (int l = L; l < kMaxGramLayers; ++l) {
+    hb.c[l] = hb.c[L - 1];
+    hb.scale[l] = 0.0;
+  }
+  return HECKA_OK;
+}
+
+int hecka_head_fwd_batched_f32(const float* S, const float* nsq, int L, int Ma, int Mb, int row_offset, const int* kind,
+                               const double* s, const double* eps, const double* arc_eps, const int* flags,
+                               const double* scale, float* totals, void* stream) {
+  clear_error();
+  if (!S || !nsq || !totals) return fail(HECKA_EINVAL, "head_fwd_batched: null pointer%s");
+  HeadBatch hb;
+  if (int rc = head_batch(hb, L, Ma, Mb, row_offset, kind, s, eps, arc_eps, flags, scale)) return rc;
+  if ((long long)Ma * Mb >= 2048)
+    hipLaunchKernelGGL(head_fwd_batched_kernel<1024>, dim3(L), dim3(1024), 0, (hipStream_t)stream, S, nsq, Ma, Mb, hb, totals);
+  else
+    hipLaunchKernelGGL(head_fwd_batched_kernel<kHeadThreads>, dim3(L), dim3(kHeadThreads), 0, (hipStream_t)stream, S, nsq, Ma,
+                       Mb, hb, totals);
+  return check_launch("head_fwd_batched");
+}
+
+int hecka_head_bwd_batched_f32(const float* S, const float* nsq, int L, int Ma, int Mb, int row_offset, const int* kind,
+                               const double* s, const double* eps, const double* arc_eps, const int* flags,
+                               const double* scale, const float* up_scalar, float* A, void* stream) {
+  clear_error();
+  if (!S || !nsq || !A) return fail(HECKA_EINVAL, "head_bwd_batched: null pointer%s");
+  HeadBatch hb;
+  if (int rc = head_batch(hb, L, Ma, Mb, row_offset, kind, s, eps, arc_eps, flags, scale)) return rc;
+  hipLaunchKernelGGL(head_bwd_batched_kernel, dim3((Ma + kHeadThreads / 64 - 1) / (kHeadThreads / 64), L), dim3(kHeadThreads),
+                     0, (hipStream_t)stream, S, nsq, Ma, Mb, hb, up_scalar, A);
+  return check_launch("head_bwd_batched");
+}
+
+int hecka_coef_gamma_batched_f32(const float* A, const float* cvec, int L, int Ma, int Mb, int B, float* gamma,
+                                 void* stream) {
+  clear_error();
+  if (!A || !cvec || !gamma) return fail(HECKA_EINVAL, "coef_gamma_batched: null pointer%s");
+  if (L <= 0 || L > 65535 || Ma <= 0 || Mb <= 0 || B <= 0 || Ma > 65535) return fail(HECKA_EINVAL, "coef_gamma_batched: bad size%s");
+  hipLaunchKernelGGL(coef_gamma_kernel, dim3((B + 255) / 256, Ma, L), dim3(256), 0, (hipStream_t)stream, A, cvec, Ma, Mb, B,
+                     gamma);
+  return check_launch("coef_gamma_batched");
+}
+
+int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamma, int L, int Ma, int Mb, int B,
+                             float* wbound, void* stream) {
+  clear_error();
+  if (!A || !nsq || !gamma || !wbound) return fail(HECKA_EINVAL, "wbound_batched: null pointer%s");
+  if (L <= 0 || L > 65535 || Ma <= 0 || Mb <= 0 || B <= 0) return fail(HECKA_EINVAL, "wbound_batched: bad size%s");
+  hipLaunchKernelGGL(wbound_kernel, dim3(Ma, L), dim3(256), 0, (hipStream_t)stream, A, nsq, gamma, Mb, B, wbound);
+  return check_launch("wbound_batched");
 }
 
 int hecka_rbf_bandwidth_f32(const float* G, int M, int B, float param, float* hband, void* stream) {

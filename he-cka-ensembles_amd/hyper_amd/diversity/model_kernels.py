@@ -308,6 +308,37 @@ class ModelLayersKernel(BaseModelKernel):
         with torch.no_grad():
             return ops.centered_gram_multi([x.detach() for x in Xs])
 
+    def _fused_layers(self, kerns, flist, layer_track):
+        """The whole weighted sum in ONE autograd node (ops.DiversityLayers: one Gram launch, one head launch, one
+        head_bwd / gamma / bound launch for all layers), or None when some layer is not on the fused linear path, the
+        shapes are not interior, a layer weight is a tensor, or the layers disagree on detach_diag."""
+        if os.environ.get('HECKA_FUSED_LAYERS', '1') == '0' or os.environ.get('HECKA_MULTI_GRAM', '1') == '0':
+            return None
+        if self.reduction not in ('mean', 'sum') or self.num_streams > 1:
+            return None
+        if not all(isinstance(k, _PairwiseHead) and k.shares_gram_launch() for k in kerns):
+            return None
+        total = len(flist)
+        weights = [self.layer_weighting.get_weight(index, total) for index in range(total)]
+        detach = {k.feature_kernel.detach_diag for k in kerns}
+        if any(isinstance(w, torch.Tensor) for w in weights) or len(detach) != 1:
+            return None
+        Xs = [ops._features(FeatureKernel.flatten(f)) for f in flist]
+        if not ops.multi_gram_eligible(Xs):
+            return None
+        M = Xs[0].shape[0]
+        specs = [k._spec() for k in kerns]
+        scales = []
+        for w, spec in zip(weights, specs):
+            count = (M * (M - 1) if spec.remove_diag else M * M) if self.reduction == 'mean' else 1
+            scales.append(float(w) / count if count else float('nan'))
+        res = ops.diversity_layers(Xs, specs, scales, detach.pop())
+        out, S_all, nsq_all = res[0], res[1], res[2]
+        for index in range(total):
+            layer_track[index]['gram'] = res[3 + index]
+            layer_track[index]['gram_inner'] = (S_all[index], nsq_all[index])
+        return out
+
     def forward(self, params, feats, pred, track):
         total = len(feats)
         if total == 0:
@@ -317,6 +348,11 @@ class ModelLayersKernel(BaseModelKernel):
         layer_track = [OrderedDict() for _ in range(total)]
         flist = list(feats.values())
         kerns = [self.layer_kernel[i] if self.different_kernels else self.layer_kernel for i in range(total)]
+        if flist[0].is_cuda:
+            out = self._fused_layers(kerns, flist, layer_track)
+            if out is not None:
+                track['layer_track'] = layer_track
+                return out
         nstream = min(self.num_streams, total) if flist[0].is_cuda else 0
         pre = self._shared_grams(kerns, flist) if flist[0].is_cuda else None
         values = []

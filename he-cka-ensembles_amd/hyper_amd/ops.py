@@ -151,12 +151,13 @@ def centered_gram_multi(Xs):
     if any(X.dtype != Xs[0].dtype for X in Xs):
         raise RuntimeError('centered_gram_multi: all layers need one feature dtype')
     out = []
-    for X in Xs:
+    cvec_all = torch.empty((len(Xs), M, B), device=dev, dtype=torch.float32)   # one tensor: the batched gamma stage reads it whole
+    for li, X in enumerate(Xs):
         P = X.shape[2]
         sbar = torch.empty((M, P), device=dev, dtype=torch.float32)
         xmax = torch.empty((M,), device=dev, dtype=torch.float32)
         C = torch.empty((M, B, B), device=dev, dtype=torch.float32)
-        cvec = torch.empty((M, B), device=dev, dtype=torch.float32)
+        cvec = cvec_all[li]
         _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
         out.append((C, cvec, xmax, sbar))
     n = len(Xs)
@@ -168,13 +169,15 @@ def centered_gram_multi(Xs):
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
 
 
-def pairwise_inner(Ca, Cb=None):
-    """S[i,j] = <Ca[i], Cb[j]> over all trailing dims; no autograd."""
+def pairwise_inner(Ca, Cb=None, out=None):
+    """S[i,j] = <Ca[i], Cb[j]> over all trailing dims; no autograd.  out: a contiguous [Ma,Mb] fp32 tensor to fill."""
     L = _lib.lib()
     Cb = Ca if Cb is None else Cb
     Ma, Mb = Ca.shape[0], Cb.shape[0]
     K = Ca[0].numel()
-    S = torch.empty((Ma, Mb), device=Ca.device, dtype=torch.float32)
+    S = out if out is not None else torch.empty((Ma, Mb), device=Ca.device, dtype=torch.float32)
+    if out is not None and (tuple(out.shape) != (Ma, Mb) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise RuntimeError('pairwise_inner: out must be a contiguous fp32 [%d,%d] tensor' % (Ma, Mb))
     nbytes = L.hecka_pairwise_workspace_bytes(Ma, Mb, K)
     ws = torch.empty((max(nbytes, 4) // 4,), device=Ca.device, dtype=torch.float32)
     _lib.check(L.hecka_pairwise_f32(_p(Ca), Ma, _p(Cb), Mb, K, _p(S), _p(ws), nbytes, _stream()), 'pairwise')
@@ -253,6 +256,121 @@ def gram_bwd_w(W, X, wmax=None, xmax=None):
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
     _GemmChain.leave(X.device, gate)
     return dX
+
+
+def _stacked(ts):
+    """[L, ...] tensor of the given L tensors: their common base when they are its consecutive slices, else a copy."""
+    base = ts[0]._base
+    if (base is not None and base.is_contiguous() and base.shape[0] == len(ts) and
+            all(t._base is base and t.data_ptr() == base[i].data_ptr() and t.shape == base.shape[1:] for i, t in enumerate(ts))):
+        return base
+    return torch.stack(ts)
+
+
+def _spec_arrays(specs, scales):
+    import ctypes
+    n = len(specs)
+    return ((ctypes.c_int * n)(*[s.kind for s in specs]), (ctypes.c_double * n)(*[s.s for s in specs]),
+            (ctypes.c_double * n)(*[s.eps for s in specs]), (ctypes.c_double * n)(*[s.arc_eps for s in specs]),
+            (ctypes.c_int * n)(*[s.flags for s in specs]), (ctypes.c_double * n)(*[float(x) for x in scales]))
+
+
+def head_forward_batched(S_all, nsq_all, row_offset, specs, scales):
+    """S_all [L,Ma,Mb], nsq_all [L,Mb] -> totals [L] = scale_l * sum of layer l's selected values (one launch)."""
+    Ln, Ma, Mb = S_all.shape
+    totals = torch.empty((Ln,), device=S_all.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_head_fwd_batched_f32(_p(S_all), _p(nsq_all), Ln, Ma, Mb, int(row_offset),
+                                                    *_spec_arrays(specs, scales), _p(totals), _stream()), 'head_fwd_batched')
+    return totals
+
+
+def head_backward_batched(S_all, nsq_all, row_offset, specs, up_scalar, scales):
+    """Coefficient matrices A_all [L,Ma,Mb] for the upstream *up_scalar * scale_l (one launch)."""
+    Ln, Ma, Mb = S_all.shape
+    A = torch.empty((Ln, Ma, Mb), device=S_all.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_head_bwd_batched_f32(_p(S_all), _p(nsq_all), Ln, Ma, Mb, int(row_offset),
+                                                    *_spec_arrays(specs, scales),
+                                                    _p(up_scalar) if up_scalar is not None else None, _p(A), _stream()),
+               'head_bwd_batched')
+    return A
+
+
+def coef_gamma_batched(A_all, cvec_all):
+    Ln, Ma, Mb = A_all.shape
+    B = cvec_all.shape[2]
+    gamma = torch.empty((Ln, Ma, B), device=A_all.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_coef_gamma_batched_f32(_p(A_all), _p(cvec_all), Ln, Ma, Mb, B, _p(gamma), _stream()),
+               'coef_gamma_batched')
+    return gamma
+
+
+def wbound_batched(A_all, nsq_all, gamma_all):
+    Ln, Ma, Mb = A_all.shape
+    out = torch.empty((Ln, Ma), device=A_all.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_wbound_batched_f32(_p(A_all), _p(nsq_all), _p(gamma_all), Ln, Ma, Mb, gamma_all.shape[2],
+                                                  _p(out), _stream()), 'wbound_batched')
+    return out
+
+
+def combine_full(A, C, gamma, detach_diag):
+    """W [Ma,B,B] = 2 sum_j A_ij C_j + gamma_i 1^T - 1 gamma_i^T (diag masked); no maximum pass."""
+    Ma, Mb = A.shape
+    B = C.shape[1]
+    W = torch.empty((Ma, B, B), device=C.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W), None,
+                                           _stream()), 'combine')
+    return W
+
+
+class DiversityLayers(torch.autograd.Function):
+    """ALL tracked layers of a `model_layers` loss in one autograd node (linear centred Grams, he / cka heads, mean / sum
+    reduction, host-float layer weights):
+        forward : column means, ONE Gram launch, pairwise per layer, ONE head launch -> sum_l w_l reduce(values_l)
+        backward: ONE head_bwd launch, ONE gamma launch, ONE bound launch, then combine + dX GEMM per layer.
+    Returns (loss, S_all [L,M,M], nsq_all [L,M], C_0 .. C_{L-1}); everything but the loss is a non-differentiable
+    by-product for `track` (the `ckas` metric reads S / nsq, hyper/experiments/metrics.py:75-91 reads the Grams)."""
+
+    @staticmethod
+    def forward(ctx, cfg, *Xs):
+        specs, scales, detach_diag, pre = cfg
+        Ln, M = len(Xs), Xs[0].shape[0]
+        Xs = [X.contiguous() for X in Xs]
+        if pre is None:
+            pre = centered_gram_multi(Xs)
+        Cs = [p[0] for p in pre]
+        cv_all = _stacked([p[1] for p in pre])
+        S_all = torch.empty((Ln, M, M), device=Xs[0].device, dtype=torch.float32)
+        for li, C in enumerate(Cs):
+            pairwise_inner(C, out=S_all[li])
+        nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()
+        totals = head_forward_batched(S_all, nsq_all, 0, specs, scales)
+        ctx.save_for_backward(*Xs, *Cs, *[p[2] for p in pre], cv_all, S_all, nsq_all)
+        ctx.cfg = (specs, scales, bool(detach_diag), Ln)
+        ctx.mark_non_differentiable(S_all, nsq_all, *Cs)
+        ctx.set_materialize_grads(False)
+        return (totals.sum(), S_all, nsq_all) + tuple(Cs)
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        specs, scales, detach_diag, Ln = ctx.cfg
+        t = ctx.saved_tensors
+        Xs, Cs, xmaxs = t[:Ln], t[Ln:2 * Ln], t[2 * Ln:3 * Ln]
+        cv_all, S_all, nsq_all = t[3 * Ln:]
+        if dout is None:
+            return (None,) + tuple(torch.zeros_like(X) for X in Xs)
+        dout = dout.contiguous().float()
+        A_all = head_backward_batched(S_all, nsq_all, 0, specs, dout, scales)
+        gamma_all = coef_gamma_batched(A_all, cv_all)
+        wmax_all = wbound_batched(A_all, nsq_all, gamma_all)
+        grads = []
+        for li in range(Ln):
+            W = combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag)
+            grads.append(gram_bwd_w(W, Xs[li], wmax_all[li], xmaxs[li]))
+        return (None,) + tuple(grads)
+
+
+def diversity_layers(Xs, specs, scales, detach_diag=True, pre=None):
+    return DiversityLayers.apply((list(specs), [float(x) for x in scales], bool(detach_diag), pre), *Xs)
 
 
 class CenteredGramPairwise(torch.autograd.Function):

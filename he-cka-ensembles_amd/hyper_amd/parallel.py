@@ -123,15 +123,22 @@ class _SlicedLayers(torch.autograd.Function):
         S_all = torch.stack(parts)                                               # [L, M, M]
         if world > 1:
             _all_reduce(S_all, group)
-        total, saved = None, []
-        for li, (X, spec, wl) in enumerate(zip(feats, specs, weights)):
-            S = S_all[li]
-            nsq = torch.diagonal(S).contiguous()
+        total, saved, scales = None, [], []
+        for spec, wl in zip(specs, weights):
             count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
-            scale = float(wl) / count if count else float('nan')
-            _, part = backend.head_forward(S, nsq, 0, spec, scale)
-            total = part if total is None else total + part
-            saved.append((X, slices[li][0], cv_all[li], S, nsq, spec, scale, xmaxs[li]))
+            scales.append(float(wl) / count if count else float('nan'))
+        batched = len(specs) <= 16 and all(hasattr(backend, f) for f in
+                                           ('head_forward_batched', 'head_backward_batched', 'coef_gamma_batched'))
+        nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()
+        if batched:                 # one head launch for all layers
+            total = backend.head_forward_batched(S_all, nsq_all, 0, specs, scales).sum()
+        for li, (X, spec) in enumerate(zip(feats, specs)):
+            S, nsq = S_all[li], nsq_all[li]
+            if not batched:
+                _, part = backend.head_forward(S, nsq, 0, spec, scales[li])
+                total = part if total is None else total + part
+            saved.append((X, slices[li][0], cv_all[li], S, nsq, spec, scales[li], xmaxs[li]))
+        ctx.batch = (S_all, nsq_all, cv_all, specs, scales) if batched else None
         ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
         ctx.geom = (world, rank, Ml, B, bounds, ns)
         return total.clone()
@@ -143,9 +150,16 @@ class _SlicedLayers(torch.autograd.Function):
         r0, n_r, N2 = rank * Ml, ns[rank], B * B
         dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
         pending = []
-        for X, Cs, cv_all, S, nsq, spec, scale, xmax in ctx.saved:
-            A = be.head_backward(S, nsq, 0, spec, dloss, scale)                  # [M, M], the same on every rank
-            gamma = be.coef_gamma(A, cv_all)                                     # [M, B]
+        if ctx.batch is not None:   # one head_bwd and one gamma launch for all layers
+            S_all, nsq_all, cv_stack, specs, scales = ctx.batch
+            A_all = be.head_backward_batched(S_all, nsq_all, 0, specs, dloss, scales)
+            gamma_all = be.coef_gamma_batched(A_all, cv_stack)
+        for li, (X, Cs, cv_all, S, nsq, spec, scale, xmax) in enumerate(ctx.saved):
+            if ctx.batch is not None:
+                A, gamma = A_all[li], gamma_all[li]
+            else:
+                A = be.head_backward(S, nsq, 0, spec, dloss, scale)              # [M, M], the same on every rank
+                gamma = be.coef_gamma(A, cv_all)                                 # [M, B]
             Ws = be.combine_slice(A, Cs, gamma, B, bounds[rank], ctx.detach)     # [M, n_r]
             if world == 1:
                 recv, work = Ws, _Done()

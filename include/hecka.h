@@ -117,6 +117,23 @@ int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int 
 int hecka_combine_f32(const float* A, const float* C, const float* gamma, int Ma, int Mb, int B,
                       int detach_diag, float* W, float* wmax, void* stream);
 
+/* The [M,M]-sized stages for ALL tracked layers in one launch each (the reference's Python loop over layers,
+ * ModelLayersKernel.forward, model_kernels.py:446-478, is L launch trains of problems far smaller than a launch):
+ * S [L,Ma,Mb], nsq [L,Mb], A [L,Ma,Mb], cvec [L,Mb,B], gamma [L,Ma,B], wbound [L,Ma] contiguous over the layer index;
+ * kind / s / eps / arc_eps / flags / scale are HOST arrays of L per-layer settings (L <= 16 for the heads).
+ * head_fwd_batched: totals[l] = scale[l] * sum of layer l's values (layer weight and 1/count folded into scale[l]).
+ * head_bwd_batched: upstream (up_scalar ? *up_scalar : 1) * scale[l]. */
+int hecka_head_fwd_batched_f32(const float* S, const float* nsq, int L, int Ma, int Mb, int row_offset, const int* kind,
+                               const double* s, const double* eps, const double* arc_eps, const int* flags,
+                               const double* scale, float* totals, void* stream);
+int hecka_head_bwd_batched_f32(const float* S, const float* nsq, int L, int Ma, int Mb, int row_offset, const int* kind,
+                               const double* s, const double* eps, const double* arc_eps, const int* flags,
+                               const double* scale, const float* up_scalar, float* A, void* stream);
+int hecka_coef_gamma_batched_f32(const float* A, const float* cvec, int L, int Ma, int Mb, int B, float* gamma,
+                                 void* stream);
+int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamma, int L, int Ma, int Mb, int B,
+                             float* wbound, void* stream);
+
 /* hecka_combine_f32 on a column slice of the flattened Gram: Cs [Mb, n_count] holds the elements
  * [n_start, n_start + n_count) of every C_j (row-major B*B), Ws [Ma, n_count] receives the same elements of every W_i.
  * For the member-sharded multi-GPU path (hyper_amd/parallel.py), where rank r holds a B*B/G slice of ALL members'

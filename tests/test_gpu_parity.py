@@ -533,8 +533,10 @@ def test_resnet_train_step_matches_reference_golden():
 
 @pytest.mark.parametrize('M,B,dims', [(8, 128, (64, 272, 32)), (5, 256, (48, 16))])
 def test_all_layers_gram_launch_matches_per_layer_and_oracle(M, B, dims, monkeypatch):
-    """hecka_gram_center_multi_f32 (every layer's centred Gram in one launch, deepest first) through
-    ModelLayersKernel: identical track['gram'] / loss / dX to the per-layer launches, and to the oracle at RTOL."""
+    """Three routes through ModelLayersKernel: 'fused' (ops.DiversityLayers: one autograd node, one Gram / head /
+    head_bwd / gamma / bound launch for all layers), 'multi' (per-layer nodes fed by hecka_gram_center_multi_f32) and
+    'single' (per-layer launches).  multi == single bit for bit; fused has the same Grams and differs from them only
+    in where the layer weight is multiplied in (1e-6); all match the oracle at RTOL."""
     from collections import OrderedDict
     from oracle import hecka_ref as R
     from hyper_amd import ops
@@ -546,23 +548,31 @@ def test_all_layers_gram_launch_matches_per_layer_and_oracle(M, B, dims, monkeyp
     torch.manual_seed(M + B)
     base = [torch.relu(torch.randn(M, B, p) + 0.2) for p in dims]
     res = {}
-    for mode in ('1', '0'):
-        monkeypatch.setenv('HECKA_MULTI_GRAM', mode)
+    for mode, (fused, multi) in {'fused': ('1', '1'), 'multi': ('0', '1'), 'single': ('0', '0')}.items():
+        monkeypatch.setenv('HECKA_FUSED_LAYERS', fused)
+        monkeypatch.setenv('HECKA_MULTI_GRAM', multi)
         xs = [b.to(dev).requires_grad_(True) for b in base]
         assert ops.multi_gram_eligible([x.detach() for x in xs])
         track = OrderedDict()
         out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
         out.backward()
-        res[mode] = (out.item(), [x.grad.cpu() for x in xs], [t['gram'].cpu() for t in track['layer_track']])
-    assert res['1'][0] == res['0'][0]
-    for a, b in zip(res['1'][1] + res['1'][2], res['0'][1] + res['0'][2]):
+        res[mode] = (out.item(), [x.grad.cpu() for x in xs], [t['gram'].cpu() for t in track['layer_track']],
+                     [t['gram_inner'][0].cpu() for t in track['layer_track']])
+    assert res['multi'][0] == res['single'][0]
+    for a, b in zip(res['multi'][1] + res['multi'][2], res['single'][1] + res['single'][2]):
         assert torch.equal(a, b)
+    assert abs(res['fused'][0] - res['single'][0]) <= 1e-6 * abs(res['single'][0])
+    for a, b in zip(res['fused'][2] + res['fused'][3], res['single'][2] + res['single'][3]):
+        assert torch.equal(a, b)                     # Grams and their inner products: the same kernels
+    for a, b in zip(res['fused'][1], res['single'][1]):
+        assert _relerr(a.numpy(), b.double().numpy()) <= 1e-6
     xo = [b.double().requires_grad_(True) for b in base]
     ref = R.run_config(cfg, xo)
     ref.backward()
-    assert abs(res['1'][0] - ref.item()) <= RTOL * abs(ref.item())
-    for g, o in zip(res['1'][1], xo):
-        assert _relerr(g.numpy(), o.grad.numpy()) <= RTOL
+    for mode in ('fused', 'single'):
+        assert abs(res[mode][0] - ref.item()) <= RTOL * abs(ref.item())
+        for g, o in zip(res[mode][1], xo):
+            assert _relerr(g.numpy(), o.grad.numpy()) <= RTOL
 
 
 def test_svgd_step_matches_reference_golden():
