@@ -505,6 +505,8 @@ __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __res
                                                                float* __restrict__ part) {
   __shared__ float red[3][16][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, kh = lane >> 5;
+  C += (size_t)blockIdx.y * 64 * K;                       // blockIdx.y: layer of a batched call
+  part += (size_t)blockIdx.y * gridDim.x * 4096;
   const long long nsteps = K / 32;
   const long long s0 = ((long long)blockIdx.x * 8 + wave) * steps_per_wave;
   long long s1 = s0 + steps_per_wave;
@@ -583,6 +585,8 @@ __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __res
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, int n,
                                                             float* __restrict__ S, float alpha) {
   __shared__ float red[16][17];
+  part += (size_t)blockIdx.y * nsplit * n;                // blockIdx.y: layer of a batched call
+  S += (size_t)blockIdx.y * n;
   const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + o;
   float s = 0.f;
@@ -1628,6 +1632,25 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   const int n = Ma * Mb;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, nsplit, n, S, 1.0f);
   return check_launch("pairwise_reduce");
+}
+
+int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long K, float* S_all, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  clear_error();
+  if (!C_all || !S_all || !ws) return fail(HECKA_EINVAL, "pairwise_self_batched: null pointer%s");
+  if (L <= 0 || L > 65535 || M != 64 || K <= 0 || K % 32 != 0 || 64 * K * 4 >= (1ll << 31) || !aligned16(C_all))
+    return fail(HECKA_EINVAL, "pairwise_self_batched: needs M == 64, K %% 32 == 0, 64 K floats < 2 GiB (K = %lld)%s", "", K);
+  const int nsplit = pairwise_nsplit(M, M, K);
+  if (ws_bytes < (size_t)L * nsplit * M * M * sizeof(float))
+    return fail(HECKA_EWORKSPACE, "pairwise_self_batched: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const long long nsteps = K / 32;
+  const int spw = (int)((nsteps + (long long)nsplit * 8 - 1) / ((long long)nsplit * 8));
+  hipLaunchKernelGGL(pairwise_self64_kernel, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws);
+  if (int rc = check_launch("pairwise_self_batched")) return rc;
+  const int n = M * M;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, nsplit, n, S_all, 1.0f);
+  return check_launch("pairwise_self_batched (reduce)");
 }
 
 int hecka_coef_gamma_f32(const float* A, const float* cvec, int Ma, int Mb, int B, float* gamma, void* stream) {

@@ -152,11 +152,12 @@ def centered_gram_multi(Xs):
         raise RuntimeError('centered_gram_multi: all layers need one feature dtype')
     out = []
     cvec_all = torch.empty((len(Xs), M, B), device=dev, dtype=torch.float32)   # one tensor: the batched gamma stage reads it whole
+    C_all = torch.empty((len(Xs), M, B, B), device=dev, dtype=torch.float32)   # likewise for the batched pairwise stage
     for li, X in enumerate(Xs):
         P = X.shape[2]
         sbar = torch.empty((M, P), device=dev, dtype=torch.float32)
         xmax = torch.empty((M,), device=dev, dtype=torch.float32)
-        C = torch.empty((M, B, B), device=dev, dtype=torch.float32)
+        C = C_all[li]
         cvec = cvec_all[li]
         _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
         out.append((C, cvec, xmax, sbar))
@@ -340,8 +341,16 @@ class DiversityLayers(torch.autograd.Function):
         Cs = [p[0] for p in pre]
         cv_all = _stacked([p[1] for p in pre])
         S_all = torch.empty((Ln, M, M), device=Xs[0].device, dtype=torch.float32)
-        for li, C in enumerate(Cs):
-            pairwise_inner(C, out=S_all[li])
+        K = Cs[0][0].numel()
+        if M == 64 and K % 32 == 0 and 64 * K * 4 < 2 ** 31:      # one pairwise launch for all layers
+            lib = _lib.lib()
+            nbytes = Ln * lib.hecka_pairwise_workspace_bytes(M, M, K)
+            ws = torch.empty((max(nbytes, 4) // 4,), device=S_all.device, dtype=torch.float32)
+            _lib.check(lib.hecka_pairwise_self_batched_f32(_p(_stacked(Cs)), Ln, M, K, _p(S_all), _p(ws), nbytes, _stream()),
+                       'pairwise_self_batched')
+        else:
+            for li, C in enumerate(Cs):
+                pairwise_inner(C, out=S_all[li])
         nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()
         totals = head_forward_batched(S_all, nsq_all, 0, specs, scales)
         ctx.save_for_backward(*Xs, *Cs, *[p[2] for p in pre], cv_all, S_all, nsq_all)
