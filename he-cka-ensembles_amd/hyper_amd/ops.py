@@ -313,6 +313,23 @@ def wbound_batched(A_all, nsq_all, gamma_all):
     return out
 
 
+def pairwise_self_batched_eligible(M, K):
+    return M == 64 and K > 0 and K % 32 == 0 and 64 * K * 4 < 2 ** 31
+
+
+def pairwise_self_batched(C_all):
+    """C_all [L,64,...] contiguous -> S_all [L,64,64] = C_l C_l^T, one launch for all layers."""
+    Ln, M = C_all.shape[0], C_all.shape[1]
+    K = C_all[0, 0].numel()
+    lib = _lib.lib()
+    S_all = torch.empty((Ln, M, M), device=C_all.device, dtype=torch.float32)
+    nbytes = Ln * lib.hecka_pairwise_workspace_bytes(M, M, K)
+    ws = torch.empty((max(nbytes, 4) // 4,), device=C_all.device, dtype=torch.float32)
+    _lib.check(lib.hecka_pairwise_self_batched_f32(_p(C_all), Ln, M, K, _p(S_all), _p(ws), nbytes, _stream()),
+               'pairwise_self_batched')
+    return S_all
+
+
 def combine_full(A, C, gamma, detach_diag):
     """W [Ma,B,B] = 2 sum_j A_ij C_j + gamma_i 1^T - 1 gamma_i^T (diag masked); no maximum pass."""
     Ma, Mb = A.shape
@@ -340,15 +357,9 @@ class DiversityLayers(torch.autograd.Function):
             pre = centered_gram_multi(Xs)
         Cs = [p[0] for p in pre]
         cv_all = _stacked([p[1] for p in pre])
-        S_all = torch.empty((Ln, M, M), device=Xs[0].device, dtype=torch.float32)
-        K = Cs[0][0].numel()
-        if M == 64 and K % 32 == 0 and 64 * K * 4 < 2 ** 31:      # one pairwise launch for all layers
-            lib = _lib.lib()
-            nbytes = Ln * lib.hecka_pairwise_workspace_bytes(M, M, K)
-            ws = torch.empty((max(nbytes, 4) // 4,), device=S_all.device, dtype=torch.float32)
-            _lib.check(lib.hecka_pairwise_self_batched_f32(_p(_stacked(Cs)), Ln, M, K, _p(S_all), _p(ws), nbytes, _stream()),
-                       'pairwise_self_batched')
-        else:
+        S_all = pairwise_self_batched(_stacked(Cs)) if pairwise_self_batched_eligible(M, Cs[0][0].numel()) else None
+        if S_all is None:
+            S_all = torch.empty((Ln, M, M), device=Xs[0].device, dtype=torch.float32)
             for li, C in enumerate(Cs):
                 pairwise_inner(C, out=S_all[li])
         nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()

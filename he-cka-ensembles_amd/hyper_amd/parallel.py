@@ -91,6 +91,8 @@ class _SlicedLayers(torch.autograd.Function):
         multi = getattr(backend, 'multi_gram_eligible', None)
         pre = backend.centered_gram_multi(feats) if multi is not None and multi(feats) else None
         slices, cvecs, xmaxs = [], [], []
+        # every layer's column slice in ONE buffer: the batched pairwise stage reads it whole
+        Cs_all = None
         for li, X in enumerate(feats):
             if X.shape[0] != Ml or X.shape[1] != B:
                 raise ValueError('every layer needs the same members and samples')
@@ -103,7 +105,9 @@ class _SlicedLayers(torch.autograd.Function):
                     send = C2.view(Ml, world, n_r).permute(1, 0, 2).contiguous().view(-1)
                 else:
                     send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
-                Cs = torch.empty((M, n_r), device=C.device, dtype=C.dtype)
+                if Cs_all is None:
+                    Cs_all = torch.empty((len(feats), M, n_r), device=C.device, dtype=C.dtype)
+                Cs = Cs_all[li]
                 slices.append((Cs, _all_to_all(Cs.view(-1), send, [Ml * n_r] * world, [Ml * n for n in ns], group)))
             cvecs.append(cvec)
             xmaxs.append(xmax)
@@ -115,12 +119,14 @@ class _SlicedLayers(torch.autograd.Function):
             raw = torch.empty((world, L, Ml, B), device=cv_loc.device, dtype=cv_loc.dtype)
             _all_gather(raw.view(-1), cv_loc.view(-1), group).wait()
             cv_all = raw.permute(1, 0, 2, 3).reshape(L, M, B).contiguous()
-        parts = []
-        for Cs, work in slices:
+        for _, work in slices:
             work.wait()
-            parts.append(backend.pairwise_inner(Cs) if n_r else
-                         torch.zeros((M, M), device=Cs.device, dtype=Cs.dtype))
-        S_all = torch.stack(parts)                                               # [L, M, M]
+        elig = getattr(backend, 'pairwise_self_batched_eligible', None)
+        if world > 1 and elig is not None and elig(M, n_r):
+            S_all = backend.pairwise_self_batched(Cs_all)                        # one launch for all layers
+        else:
+            S_all = torch.stack([backend.pairwise_inner(Cs) if n_r else
+                                 torch.zeros((M, M), device=Cs.device, dtype=Cs.dtype) for Cs, _ in slices])   # [L, M, M]
         if world > 1:
             _all_reduce(S_all, group)
         total, saved, scales = None, [], []
