@@ -1435,7 +1435,7 @@ using namespace hecka;
 
 extern "C" {
 
-int hecka_version(void) { return 3; }
+int hecka_version(void) { return 4; }
 
 static int g_gemm_mode = 0;
 int hecka_set_gemm_mode(int mode) {
