@@ -174,7 +174,7 @@ def main():
             'roofline': dict({'bound': 'mfma', 'kernel': kname, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                               'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': traffic}, **hw),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             out['cpu_baseline'] = cpu_baseline()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

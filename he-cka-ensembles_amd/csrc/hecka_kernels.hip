@@ -493,9 +493,11 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
 }
 
 // Streaming form of S = C C^T for the common shape (Ca == Cb, exactly 64 rows, K % 32 == 0): the LDS-tiled core above
-// moves every element through LDS for a 64 x 64 output that needs no sharing between waves.  Here every wave streams its
-// own K range straight from HBM into MFMA fragments: lane (r, kh) loads C[r][k .. k+3] and C[32+r][k .. k+3] at
-// k = 8 g + 4 kh - for v_mfma_f32_32x32x2_f32 the A fragment of row block R and the B fragment of column block R are the
+// synchronises a workgroup around a 64 x 64 output that needs no sharing between waves.  Here every wave streams its
+// own K range: whole 128-byte lines of the 64 rows into a wave-private LDS tile (no barrier), and from there lane (r, kh)
+// reads C[r][k .. k+3] and C[32+r][k .. k+3] at k = 8 g + 4 kh as MFMA fragments (loading those 16-byte pieces straight
+// from HBM touched a quarter of 32 lines per instruction and thrashed L1: 143 us for five layers) - for
+// v_mfma_f32_32x32x2_f32 the A fragment of row block R and the B fragment of column block R are the
 // SAME registers (A: lane (i, k) holds C[i][k]; B = C^T: lane (j, k) holds C[j][k]), and any two k shared by A and B make
 // a valid k-pair, so element e of the two quads gives one MFMA per output block: blocks 00, 01, 11 (10 is 01 transposed).
 // 512 threads (two waves per SIMD), next step's loads in flight during the 48 MFMAs of the current one; the eight waves'
@@ -503,7 +505,11 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
 // as before).  fp32-MFMA-bound: 1.6 GFLOP at M = 64, B = 512.
 __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __restrict__ C, long long K, int steps_per_wave,
                                                                float* __restrict__ part) {
-  __shared__ float red[3][16][64];
+  // per-wave staging tile: 64 rows x 32 k (128 B) at a 144-byte pitch (conflict-free ds_read_b128 down a column of rows);
+  // the reduction buffer at the end reuses the same memory
+  constexpr int kPitch = 36;                       // floats
+  __shared__ float stage[8][64 * kPitch];
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(&stage[0][0]);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, kh = lane >> 5;
   C += (size_t)blockIdx.y * 64 * K;                       // blockIdx.y: layer of a batched call
   part += (size_t)blockIdx.y * gridDim.x * 4096;
@@ -512,46 +518,53 @@ __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __res
   long long s1 = s0 + steps_per_wave;
   if (s1 > nsteps) s1 = nsteps;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C), 0, (int)(64 * K * 4), 0x00020000);
-  const unsigned v0 = (unsigned)r * (unsigned)K * 4u + (unsigned)kh * 16u;
-  const unsigned v1 = v0 + 32u * (unsigned)K * 4u;
-  f32x4 fr[2][2][4];   // [set][row block][8-k group of the step]
-  auto load = [&](auto SET, long long st) __attribute__((always_inline)) {
-    constexpr int S = decltype(SET)::value;
+  // global loads in whole 128-byte lines: lane l takes 16 bytes (segment l & 7) of row 8 i + (l >> 3), i = 0..7
+  const unsigned vg = (unsigned)(lane >> 3) * (unsigned)K * 4u + (unsigned)(lane & 7) * 16u;
+  const unsigned rstep = 8u * (unsigned)K * 4u;
+  float* mine = stage[wave];
+  const int wofs = (lane >> 3) * kPitch + (lane & 7) * 4;     // + i * 8 * kPitch
+  const int rofs = r * kPitch + kh * 4;                       // + 32 * kPitch for the second row block, + 8 u
+  f32x4 g[8];
+  auto gload = [&](long long st) __attribute__((always_inline)) {
     const int so = (int)(st * 128);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      fr[S][0][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v0, so + 32 * u, 0));
-      fr[S][1][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)v1, so + 32 * u, 0));
-    }
+    for (int i = 0; i < 8; ++i)
+      g[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vg + i * rstep), so, 0));
+  };
+  auto to_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&mine[wofs + i * 8 * kPitch]) = g[i];
   };
   f32x16 acc[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
-  auto mma = [&](auto SET) __attribute__((always_inline)) {
-    constexpr int S = decltype(SET)::value;
+  long long st = s0;
+  if (st < s1) {
+    gload(st);
+    to_lds();
+  }
+  while (st < s1) {
+    if (st + 1 < s1) gload(st + 1);                 // next step's lines in flight behind this step's 48 MFMAs
+    f32x4 f0[4], f1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f0[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 8 * u]);
+      f1[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 32 * kPitch + 8 * u]);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[S][0][u][e], fr[S][0][u][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[S][0][u][e], fr[S][1][u][e], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[S][1][u][e], fr[S][1][u][e], acc[2], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f0[u][e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f1[u][e], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[u][e], f1[u][e], acc[2], 0, 0, 0);
       }
-  };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  long long st = s0;
-  if (st < s1) load(S0{}, st);
-  while (st < s1) {
-    if (st + 1 < s1) load(S1{}, st + 1);
-    mma(S0{});
-    if (++st >= s1) break;
-    if (st + 1 < s1) load(S0{}, st + 1);
-    mma(S1{});
     ++st;
+    if (st < s1) to_lds();                          // the wave's own reads above have returned: program order
   }
+  __syncthreads();                                  // the staging tiles become the reduction buffer
   // waves add their accumulators in wave order (deterministic)
   for (int w = 0; w < 8; ++w) {
     if (wave == w) {
