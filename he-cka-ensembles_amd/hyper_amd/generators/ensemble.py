@@ -50,6 +50,10 @@ class EnsembleParametersGroupGenerator(nn.Module):
         return torch.empty(num, self.flat_size, device=device).normal_(0.0, std)
 
     def forward(self, codes):
+        if getattr(codes, '_hecka_identity', False) and codes.numel() == self.fixed_size:
+            # every member, in order (the usual training step): the parameters themselves, no gather in forward and no
+            # index_add in backward
+            return torch.cat([v.view(self.fixed_size, -1) for v in self.fixed_parameters.values()], dim=1)
         idx = codes.long().ravel()
         return torch.cat([v.index_select(0, idx).view(len(idx), -1) for v in self.fixed_parameters.values()], dim=1)
 
@@ -69,12 +73,19 @@ class MemberBuffers:
         store = getattr(self.owner, name)
         return [store[i] for i in self.idx.tolist()]
 
+    def _all(self, store):
+        return getattr(self.idx, '_hecka_identity', False) and self.idx.numel() == store.shape[0]
+
     def gather(self, name):
-        return getattr(self.owner, name).index_select(0, self.idx)
+        store = getattr(self.owner, name)
+        return store if self._all(store) else store.index_select(0, self.idx)
 
     def update(self, name, value, factor):
         store = getattr(self.owner, name)
-        store.index_copy_(0, self.idx, (1 - factor) * store.index_select(0, self.idx) + factor * value)
+        if self._all(store):
+            store.mul_(1 - factor).add_(value, alpha=factor)
+        else:
+            store.index_copy_(0, self.idx, (1 - factor) * store.index_select(0, self.idx) + factor * value)
 
 
 class EnsembleBufferGroupGenerator(nn.Module):
@@ -103,7 +114,10 @@ class EnsembleBufferGroupGenerator(nn.Module):
         return MemberBuffers(fresh.to(device) if device is not None else fresh, torch.arange(num, device=device))
 
     def forward(self, codes):
-        return MemberBuffers(self, codes.long().ravel())
+        idx = codes.long().ravel()
+        if getattr(codes, '_hecka_identity', False):
+            idx._hecka_identity = True
+        return MemberBuffers(self, idx)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         for name in self.names:
@@ -166,6 +180,7 @@ class FixedEnsembleModel(nn.Module):
                 if len(cache) > 64:
                     cache.clear()
                 cache[key] = torch.tensor(list(size), device=device, dtype=torch.long)
+                cache[key]._hecka_identity = list(size) == list(range(self.size))
             return cache[key]
         return torch.randperm(self.size, device=device, dtype=torch.long)[:size]
 
@@ -191,6 +206,8 @@ class FixedEnsembleModel(nn.Module):
             if any(codes is t for t in cached.values()):
                 checked[key] = codes
         idx = codes.reshape(-1).long()
+        if getattr(codes, '_hecka_identity', False):
+            idx._hecka_identity = True
         params = DefaultOrderedDict()
         for names, gen in self._iter([], self.layer_generators):
             params.set_subitems(names, gen(idx))
