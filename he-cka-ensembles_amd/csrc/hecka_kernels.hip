@@ -886,6 +886,36 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(con
   });
 }
 
+// General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
+// fp16 range by powers of two from per-batch maxima (upper bounds are fine), optional split-K (blockIdx.y: partial
+// slabs for a fixed-order second stage).  The convolution GEMMs of the batched-weight layers at 128 and more channels.
+template <bool NN, bool FOLD>
+__global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                  float* __restrict__ C, int rows, int cols, int K,
+                                                                  long long strideA, long long strideB,
+                                                                  const float* __restrict__ amaxA,
+                                                                  const float* __restrict__ amaxB, int amaxB_stride,
+                                                                  float alpha, int tilesM, int tilesN, int kchunk,
+                                                                  long long slab) {
+  using Tile = GemmTileX6<128, 128, NN, ScaleProX6<1>, 1, FOLD>;
+  __shared__ typename Tile::Smem sm;
+  const int per = tilesM * tilesN;
+  const int b = blockIdx.x / per, tl = blockIdx.x % per;
+  const int ti = tl % tilesM, tj = tl / tilesM;
+  const int kbeg = blockIdx.y * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  ScaleProX6<1> pro;
+  pro.sa = pow2_scale(amaxA[b], 14);
+  pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
+  const float unscale = (gridDim.y > 1 ? 1.0f : alpha) / (pro.sa * pro.sb);
+  Tile tile;
+  tile.run(sm, A + (size_t)b * strideA, (unsigned)((size_t)rows * K * 4u), K, Bm + (size_t)b * strideB,
+           (unsigned)((size_t)cols * K * 4u), NN ? cols : K, ti * 128, tj * 128, kbeg, kend, pro);
+  float* out = C + (size_t)blockIdx.y * slab + (size_t)b * rows * cols;
+  tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * 128 + lr) * cols + tj * 128 + lc] = v * unscale; });
+}
+
 // ------------------------------------------------------------------------------------------
 // (7) row-wise helpers for the un-fused functional API (center_gram and its backward).
 //     HBM-bound elementwise passes over [rows, cols].
@@ -2130,6 +2160,72 @@ int hecka_bgemm_splitk_f32(const float* A, const float* Bm, float* C, int batch,
 #undef HECKA_BGEMMS
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nsplit, (int)n, C, alpha);
   return check_launch("bgemm_splitk");
+}
+
+int hecka_absmax_rows_f32(const float* V, int rows, long long n, float* out, void* stream) {
+  clear_error();
+  if (!V || !out) return fail(HECKA_EINVAL, "absmax_rows: null pointer%s");
+  if (rows <= 0 || rows > 65535 || n <= 0) return fail(HECKA_EINVAL, "absmax_rows: size out of range%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)rows * sizeof(float), st) != hipSuccess) return check_launch("absmax_rows (memset)");
+  const int chunks = (int)std::max<long long>(1, std::min<long long>(n / 65536, 1024 / rows + 1));
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, rows), dim3(256), 0, st, V, n, chunks, reinterpret_cast<unsigned*>(out));
+  return check_launch("absmax_rows");
+}
+
+static int bgemm_x3_nsplit(int batch, int rows, int cols, int K) {
+  const long long tiles = (long long)(rows / 128) * (cols / 128) * batch;
+  if (tiles >= 512 || K < 2048) return 1;
+  long long want = (1024 + tiles - 1) / tiles, maxs = K / 1024;
+  if (want > maxs) want = maxs;
+  return want >= 2 ? (int)want : 1;
+}
+
+int hecka_bgemm_x3_eligible(int batch, int rows, int cols, int K) {
+  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && cols > 0 && K > 0 && rows % 128 == 0 && cols % 128 == 0 &&
+         K % kX6BK == 0 && (long long)rows * K < (1ll << 30) && (long long)cols * K < (1ll << 30) &&
+         (long long)batch * (rows / 128) * (cols / 128) < (1ll << 31);
+}
+
+size_t hecka_bgemm_x3_workspace_bytes(int batch, int rows, int cols, int K) {
+  if (!hecka_bgemm_x3_eligible(batch, rows, cols, K)) return 0;
+  const int ns = bgemm_x3_nsplit(batch, rows, cols, K);
+  return ns > 1 ? (size_t)ns * batch * rows * cols * sizeof(float) : 0;
+}
+
+int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int rows, int cols, int K, long long strideA,
+                       long long strideB, int nn, float alpha, const float* amaxA, const float* amaxB, int amaxB_stride,
+                       void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  if (!A || !Bm || !C || !amaxA || !amaxB) return fail(HECKA_EINVAL, "bgemm_x3: null pointer%s");
+  if (!hecka_bgemm_x3_eligible(batch, rows, cols, K) || !aligned16(A) || !aligned16(Bm) || !aligned16(C) ||
+      (strideA % 4) || (strideB % 4))
+    return fail(HECKA_EINVAL, "bgemm_x3: needs HECKA_GEMM_AUTO, rows %% 128 == 0, cols %% 128 == 0, K %% 16 == 0, 16-byte alignment%s");
+  const int ns = bgemm_x3_nsplit(batch, rows, cols, K);
+  const size_t need = ns > 1 ? (size_t)ns * batch * rows * cols * sizeof(float) : 0;
+  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "bgemm_x3: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  const int tilesM = rows / 128, tilesN = cols / 128;
+  const long long ktiles = K / kX6BK;
+  const int kchunk = (int)(((ktiles + ns - 1) / ns) * kX6BK);
+  const bool fold = kchunk > 1024;
+  dim3 grid((unsigned)((long long)batch * tilesM * tilesN), ns);
+  hipStream_t st = (hipStream_t)stream;
+  float* out = ns > 1 ? (float*)ws : C;
+  const long long slab = (long long)batch * rows * cols;
+#define HECKA_BX3(NNV, FOLDV) \
+  hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, strideB, \
+                     amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab)
+  if (nn) { if (fold) HECKA_BX3(true, true); else HECKA_BX3(true, false); }
+  else { if (fold) HECKA_BX3(false, true); else HECKA_BX3(false, false); }
+#undef HECKA_BX3
+  if (int rc = check_launch("bgemm_x3")) return rc;
+  if (ns > 1) {
+    const long long n = slab;
+    if (n > 0x7fffffffLL) return fail(HECKA_EINVAL, "bgemm_x3: output too large for the split-K reduction%s");
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)n, C, alpha);
+    return check_launch("bgemm_x3 (reduce)");
+  }
+  return HECKA_OK;
 }
 
 static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,

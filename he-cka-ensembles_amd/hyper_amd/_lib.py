@@ -46,6 +46,10 @@ SIGNATURES = {
     'hecka_coef_gamma_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'hecka_wbound_batched_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'hecka_pairwise_self_batched_f32': (_i, [_vp, _i, _i, _ll, _vp, _vp, ctypes.c_size_t, _vp]),
+    'hecka_absmax_rows_f32': (_i, [_vp, _i, _ll, _vp, _vp]),
+    'hecka_bgemm_x3_eligible': (_i, [_i, _i, _i, _i]),
+    'hecka_bgemm_x3_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'hecka_bgemm_x3_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, _vp, _i, _vp, _sz, _vp]),
     'hecka_combine_slice_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'hecka_batchnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),

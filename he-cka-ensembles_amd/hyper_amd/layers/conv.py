@@ -16,7 +16,7 @@ from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 
 from .. import _lib
 from ..net import activation
-from .linear import _bgemm
+from .linear import _absmax_rows, _bgemm, _bgemm_x3, _x3_eligible
 from .module import ParametersGroup, register_gen_module
 
 
@@ -69,34 +69,51 @@ class BatchedConv2d(torch.autograd.Function):
             Wf = torch.cat([Wf, (bias_scale / scale) * b.reshape(M, O, 1)], dim=2)
         Wf = Wf.contiguous()
         R = Wf.shape[2]
-        y = _bgemm(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale)      # [M,O,Q]
+        # interior shapes without a bias row (the ResNet stages at 128 and more channels): the GEMMs run on the fp16-split
+        # tile, scaled by max |x| (the patches are copies of x) and max |W|
+        xmax = wmax = None
+        if not has_bias and (_x3_eligible(M, O, Q, R) or _x3_eligible(M, O, R, Q) or _x3_eligible(M, K, Q, O)):
+            xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
+            wmax = _absmax_rows(Wf.reshape(M, -1), M)
+        if xmax is not None and _x3_eligible(M, O, Q, R):
+            y = _bgemm_x3(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale, wmax, xmax, 0 if shared else 1)
+        else:
+            y = _bgemm(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale)      # [M,O,Q]
         # the gathered patches are kept for the weight gradient while they are small next to 288 GB of HBM (23 GB for
         # all of ResNet18 at M=10, N=128); larger ones are re-gathered in backward
         keep = cols.numel() * 4 <= int(float(os.environ.get('HECKA_CONV_KEEP_COLS_GB', '8')) * 2 ** 30)
-        ctx.save_for_backward(x5, W, cols if keep else None)
+        ctx.save_for_backward(x5, W, cols if keep else None, xmax, wmax)
         ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
         return y.view(M, O, N, Ho, Wo).transpose(1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        x5, W, cols = ctx.saved_tensors
+        x5, W, cols, xmax, wmax = ctx.saved_tensors
         scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo) = ctx.cfg
         M, O, C, kh, kw = W.shape
         K, Q = C * kh * kw, N * Ho * Wo
         dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
         dx = dW = db = None
+        dymax = _absmax_rows(dyq.view(M, -1), M) if xmax is not None else None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             if cols is None:
                 cols = _im2col(x5, geom, has_bias)
             R = cols.shape[1]
-            dWf = _bgemm(dyq, cols, M, O, R, Q, O * Q, 0 if shared else R * Q, False, scale)   # dy cols^T  [M,O,R]
+            if dymax is not None and _x3_eligible(M, O, R, Q):
+                dWf = _bgemm_x3(dyq, cols, M, O, R, Q, O * Q, 0 if shared else R * Q, False, scale, dymax, xmax,
+                                0 if shared else 1)
+            else:
+                dWf = _bgemm(dyq, cols, M, O, R, Q, O * Q, 0 if shared else R * Q, False, scale)   # dy cols^T  [M,O,R]
             dW = dWf[:, :, :K].reshape(W.shape)
             if has_bias:
                 db = dWf[:, :, K] * (bias_scale / scale)
             del cols
         if ctx.needs_input_grad[0]:
             Wt = W.reshape(M, O, K).transpose(1, 2).contiguous()                              # [M,K,O]
-            dcols = _bgemm(Wt, dyq, M, K, Q, O, K * O, O * Q, True, scale)                     # W^T dy  [M,K,Q]
+            if dymax is not None and _x3_eligible(M, K, Q, O):
+                dcols = _bgemm_x3(Wt, dyq, M, K, Q, O, K * O, O * Q, True, scale, wmax, dymax, 1)
+            else:
+                dcols = _bgemm(Wt, dyq, M, K, Q, O, K * O, O * Q, True, scale)                 # W^T dy  [M,K,Q]
             dx = _col2im(dcols, M, N, C, x5.shape[3], x5.shape[4], geom)
             dx = dx.sum(0) if shared else dx
         return dx, dW, db, None, None, None

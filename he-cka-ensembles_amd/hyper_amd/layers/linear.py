@@ -3,6 +3,8 @@
 fp32 MFMA (libhecka hecka_bgemm_f32) with the parameter scaling and the bias add folded into the epilogue."""
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 import torch.nn.init as init
@@ -25,6 +27,31 @@ def _bgemm(A, B, batch, rows, cols, K, sA, sB, nn, alpha, bias=None, beta=0.0):
     _lib.check(_lib.lib().hecka_bgemm_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), batch, rows, cols, K, sA, sB,
                                           int(nn), float(alpha), bias.data_ptr() if bias is not None else None,
                                           float(beta), torch.cuda.current_stream().cuda_stream), 'bgemm')
+    return out
+
+
+def _absmax_rows(V, rows):
+    """[rows] maxima of |V| over each of `rows` equal contiguous parts (operand scales of the fp16-split GEMM)."""
+    V = V.contiguous()
+    out = torch.empty((rows,), device=V.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_absmax_rows_f32(V.data_ptr(), rows, V.numel() // rows, out.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), 'absmax_rows')
+    return out
+
+
+def _x3_eligible(batch, rows, cols, K):
+    return os.environ.get('HECKA_CONV_X3', '1') != '0' and bool(_lib.lib().hecka_bgemm_x3_eligible(batch, rows, cols, K))
+
+
+def _bgemm_x3(A, B, batch, rows, cols, K, sA, sB, nn, alpha, amaxA, amaxB, amaxB_stride):
+    """_bgemm on the fp16-split tile (interior shapes; see hecka_bgemm_x3_f32)."""
+    out = torch.empty((batch, rows, cols), device=A.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.hecka_bgemm_x3_workspace_bytes(batch, rows, cols, K)
+    ws = torch.empty((max(nbytes, 4) // 4,), device=A.device, dtype=torch.float32)
+    _lib.check(L.hecka_bgemm_x3_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), batch, rows, cols, K, sA, sB, int(nn),
+                                    float(alpha), amaxA.data_ptr(), amaxB.data_ptr(), int(amaxB_stride), ws.data_ptr(),
+                                    nbytes, torch.cuda.current_stream().cuda_stream), 'bgemm_x3')
     return out
 
 

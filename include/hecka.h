@@ -201,6 +201,19 @@ int hecka_bgemm_splitk_f32(const float* A, const float* B, float* C, int batch, 
                            long long strideA, long long strideB, int nn, float alpha, void* ws, size_t ws_bytes,
                            void* stream);
 
+/* hecka_bgemm_f32 (no bias) on the fp16-split tile, 2.5-3x the fp32-MFMA rate, for interior shapes (rows % 128 == 0,
+ * cols % 128 == 0, K % 16 == 0; hecka_bgemm_x3_eligible): amaxA [batch] and amaxB [batch, or one value with
+ * amaxB_stride = 0 for a shared operand] are max |A[b]| / max |B[b]| or upper bounds (hecka_absmax_rows_f32: out[r] =
+ * max |V[r, 0..n)|).  Few tiles over a long K (convolution weight gradients) are split over K:
+ * hecka_bgemm_x3_workspace_bytes is non-zero then, the slabs are summed in a fixed order.  The convolution GEMMs of the
+ * batched-weight Conv2d at 128 and more channels; no counterpart in the reference (it calls F.conv2d per member). */
+int hecka_absmax_rows_f32(const float* V, int rows, long long n, float* out, void* stream);
+int hecka_bgemm_x3_eligible(int batch, int rows, int cols, int K);
+size_t hecka_bgemm_x3_workspace_bytes(int batch, int rows, int cols, int K);
+int hecka_bgemm_x3_f32(const float* A, const float* B, float* C, int batch, int rows, int cols, int K, long long strideA,
+                       long long strideB, int nn, float alpha, const float* amaxA, const float* amaxB, int amaxB_stride,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
  * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
  * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an

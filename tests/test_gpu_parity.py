@@ -725,3 +725,35 @@ def test_graphed_train_step_equals_eager():
     assert abs(finals[0][0] - finals[1][0]) <= 1e-5 * abs(finals[0][0])
     for a, b in zip(finals[0][1], finals[1][1]):
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize('N,HW,shared', [(8, 8, False), (64, 16, True)])
+def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, monkeypatch):
+    """Conv2d at 128 channels (interior shapes, no bias): forward, weight gradient (split-K in the second case) and
+    input gradient on the fp16-split batched GEMM (hecka_bgemm_x3_f32) against F.conv2d per member in fp64, and
+    against the fp32-MFMA route (HECKA_CONV_X3=0)."""
+    import torch.nn.functional as F
+    from hyper_amd.layers.conv import BatchedConv2d
+    from hyper_amd import _lib
+    dev = _dev()
+    torch.manual_seed(11)
+    M, C, O = 2, 128, 128
+    x = torch.randn((N, C, HW, HW) if shared else (M, N, C, HW, HW), device=dev)
+    W = torch.randn(M, O, C, 3, 3, device=dev) * 0.05
+    up = torch.randn(M, N, O, HW, HW, device=dev)
+    geom = (3, 3, 1, 1, 1, 1, 1, 1)
+    assert _lib.lib().hecka_bgemm_x3_eligible(M, O, N * HW * HW, C * 9)
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('HECKA_CONV_X3', mode)
+        xx, WW = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        y = BatchedConv2d.apply(xx, WW, None, 0.7, 1.0, geom)
+        (y * up).sum().backward()
+        res[mode] = (y.detach().cpu().double(), xx.grad.cpu().double(), WW.grad.cpu().double())
+    xd, Wd, upd = x.cpu().double().requires_grad_(True), W.cpu().double().requires_grad_(True), up.cpu().double()
+    yd = torch.stack([F.conv2d(xd if shared else xd[m], 0.7 * Wd[m], None, 1, 1) for m in range(M)])
+    (yd * upd).sum().backward()
+    for mode in ('1', '0'):
+        assert _relerr(res[mode][0].numpy(), yd.detach().numpy()) <= RTOL, mode
+        assert _relerr(res[mode][1].numpy(), xd.grad.numpy()) <= RTOL, mode
+        assert _relerr(res[mode][2].numpy(), Wd.grad.numpy()) <= RTOL, mode
