@@ -309,35 +309,42 @@ class ModelLayersKernel(BaseModelKernel):
             return ops.centered_gram_multi([x.detach() for x in Xs])
 
     def _fused_layers(self, kerns, flist, layer_track):
-        """The whole weighted sum in ONE autograd node (ops.DiversityLayers: one Gram launch, one head launch, one
-        head_bwd / gamma / bound launch for all layers), or None when some layer is not on the fused linear path, the
-        shapes are not interior, a layer weight is a tensor, or the layers disagree on detach_diag."""
+        """The weighted sum over the layers that can share ONE autograd node (ops.DiversityLayers: one Gram launch, one
+        head launch, one head_bwd / gamma / bound launch for all of them).  Returns (partial loss, set of layer indices it
+        covers), or (None, empty) when fewer than two layers qualify: a layer qualifies when it is on the fused linear
+        path with a host-float weight and an interior shape (a net's tiny last layer - 10 logits - must not keep its
+        64-channel feature maps from the shared launch)."""
+        none = (None, frozenset())
         if os.environ.get('HECKA_FUSED_LAYERS', '1') == '0' or os.environ.get('HECKA_MULTI_GRAM', '1') == '0':
-            return None
+            return none
         if self.reduction not in ('mean', 'sum') or self.num_streams > 1:
-            return None
-        if not all(isinstance(k, _PairwiseHead) and k.shares_gram_launch() for k in kerns):
-            return None
+            return none
         total = len(flist)
         weights = [self.layer_weighting.get_weight(index, total) for index in range(total)]
-        detach = {k.feature_kernel.detach_diag for k in kerns}
-        if any(isinstance(w, torch.Tensor) for w in weights) or len(detach) != 1:
-            return None
-        Xs = [ops._features(FeatureKernel.flatten(f)) for f in flist]
-        if not ops.multi_gram_eligible(Xs):
-            return None
-        M = Xs[0].shape[0]
-        specs = [k._spec() for k in kerns]
+        cand = [i for i in range(total) if isinstance(kerns[i], _PairwiseHead) and kerns[i].shares_gram_launch()
+                and not isinstance(weights[i], torch.Tensor)]
+        Xs = {i: ops._features(FeatureKernel.flatten(flist[i])) for i in cand}
+        groups = {}
+        for i in cand:      # one launch needs one (members, samples, dtype, detach_diag) and interior feature sizes
+            X = Xs[i]
+            if ops.multi_gram_eligible([X, X]):
+                key = (X.shape[0], X.shape[1], X.dtype, kerns[i].feature_kernel.detach_diag)
+                groups.setdefault(key, []).append(i)
+        best = max(groups.values(), key=len) if groups else []
+        if len(best) < 2 or len(best) > 16 or not ops.multi_gram_eligible([Xs[i] for i in best]):
+            return none
+        M = Xs[best[0]].shape[0]
+        specs = [kerns[i]._spec() for i in best]
         scales = []
-        for w, spec in zip(weights, specs):
+        for i, spec in zip(best, specs):
             count = (M * (M - 1) if spec.remove_diag else M * M) if self.reduction == 'mean' else 1
-            scales.append(float(w) / count if count else float('nan'))
-        res = ops.diversity_layers(Xs, specs, scales, detach.pop())
+            scales.append(float(weights[i]) / count if count else float('nan'))
+        res = ops.diversity_layers([Xs[i] for i in best], specs, scales, kerns[best[0]].feature_kernel.detach_diag)
         out, S_all, nsq_all = res[0], res[1], res[2]
-        for index in range(total):
-            layer_track[index]['gram'] = res[3 + index]
-            layer_track[index]['gram_inner'] = (S_all[index], nsq_all[index])
-        return out
+        for k, index in enumerate(best):
+            layer_track[index]['gram'] = res[3 + k]
+            layer_track[index]['gram_inner'] = (S_all[k], nsq_all[k])
+        return out, frozenset(best)
 
     def forward(self, params, feats, pred, track):
         total = len(feats)
@@ -348,11 +355,19 @@ class ModelLayersKernel(BaseModelKernel):
         layer_track = [OrderedDict() for _ in range(total)]
         flist = list(feats.values())
         kerns = [self.layer_kernel[i] if self.different_kernels else self.layer_kernel for i in range(total)]
-        if flist[0].is_cuda:
-            out = self._fused_layers(kerns, flist, layer_track)
-            if out is not None:
-                track['layer_track'] = layer_track
-                return out
+        fused_out, fused = self._fused_layers(kerns, flist, layer_track) if flist[0].is_cuda else (None, frozenset())
+        if len(fused) == total:
+            track['layer_track'] = layer_track
+            return fused_out
+        if fused:       # the remaining layers one by one, their weighted values added to the fused partial sum
+            out = fused_out
+            for index in range(total):
+                if index in fused:
+                    continue
+                value = self._layer_value(kerns[index], params, flist[index], pred, layer_track[index])
+                out = out + self.layer_weighting.get_weight(index, total) * value
+            track['layer_track'] = layer_track
+            return out
         nstream = min(self.num_streams, total) if flist[0].is_cuda else 0
         pre = self._shared_grams(kerns, flist) if flist[0].is_cuda else None
         values = []
