@@ -304,7 +304,8 @@ struct RawProX6 {
 template <int EX>
 __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                  const float* __restrict__ xmax, float* __restrict__ C,
-                                                 float* __restrict__ cvec, int B, int P, int ntile, int xcd_map, int w) {
+                                                 float* __restrict__ cvec, int B, int P, int ntile, int xcd_map, int w,
+                                                 int kbeg, int kend) {
   static_assert(EX != kElemF32, "raw Gram: 16-bit features only");
   using Tile = GemmTileX6<128, 128, false, RawProX6<1>, 1, true, EX, EX, false, false>;
   using TileD = GemmTileX6<128, 128, false, RawProX6<1>, 1, true, EX, EX, false, false, true>;   // diagonal tiles
@@ -327,7 +328,7 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   Tile tile;
   if (I == J) {
     TileD td;
-    td.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+    td.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, kbeg, kend, pro);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -335,7 +336,7 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
     pro.cbv[0] = pro.cav[0];
     pro.cbv[1] = pro.cav[1];
   } else {
-    tile.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, 0, P, pro);
+    tile.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, kbeg, kend, pro);
   }
   float ss = pro.ssv[0] + pro.ssv[1] + pro.ssv[2] + pro.ssv[3];
   ss += __shfl_xor(ss, 1);
@@ -368,7 +369,7 @@ template <int SCHEME, int EX = kElemF32>
 __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
-                                                    int w) {
+                                                    int w, int kbeg, int kend) {
   using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX>;
   using TileD = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX, true, true, true>;   // diagonal tiles
   constexpr unsigned ES = elem_bytes<EX>();
@@ -391,7 +392,7 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   Tile tile;
   if (I == J) {
     TileD td;
-    td.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
+    td.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, kbeg, kend, pro);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -399,7 +400,7 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
     pro.cbv[0] = pro.cav[0];
     pro.cbv[1] = pro.cav[1];
   } else {
-    tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, 0, P, pro);
+    tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, kbeg, kend, pro);
   }
   // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
 #pragma unroll
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float
                                                                      const float* __restrict__ xmax,
                                                                      float* __restrict__ C, float* __restrict__ cvec,
                                                                      int B, int P, int ntile, int xcd_map) {
-  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, (int)blockIdx.x);
+  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, (int)blockIdx.x, 0, P);
 }
 
 // All tracked layers in ONE launch.  A layer's Gram is M * 10 equal workgroups (B = 512) on 512 resident slots: launched
@@ -445,11 +446,39 @@ struct GramLayerArgs {
   float* cvec;
   int P;
   int wg_end;   // first workgroup of the next layer
+  // split-K (few workgroups over a deep P: small ensembles, member shards): nsplit > 1 partial Grams of kchunk features
+  // each go to the slabs Cws [nsplit,M,B,B] / cws [nsplit,M,B]; every stage of the epilogue is linear in the k range, so
+  // a fixed-order sum of the slabs (gram_split_reduce_kernel) gives C and cvec
+  int nsplit, kchunk;
+  float* Cws;
+  float* cws;
 };
 struct GramMultiArgs {
   GramLayerArgs l[kMaxGramLayers];
-  int L;
+  int L, M;
 };
+
+// C = sum_z Cws[z], cvec = sum_z cws[z] for the split layers (grid.y = layer; fixed order: deterministic)
+__global__ __launch_bounds__(256) void gram_split_reduce_kernel(GramMultiArgs a, long long nC, long long nc) {
+  const int li = blockIdx.y;
+  int nsplit = a.l[0].nsplit; const float* Cws = a.l[0].Cws; const float* cws = a.l[0].cws;
+  float* C = a.l[0].C; float* cvec = a.l[0].cvec;
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) { nsplit = a.l[i].nsplit; Cws = a.l[i].Cws; cws = a.l[i].cws; C = a.l[i].C; cvec = a.l[i].cvec; }
+  if (nsplit <= 1) return;
+  const long long q = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (q < nC) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(Cws + q);
+    for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(Cws + (size_t)z * nC + q);
+    *reinterpret_cast<f32x4*>(C + q) = s;
+  } else if (q - nC < nc) {
+    const long long r = q - nC;
+    f32x4 s = *reinterpret_cast<const f32x4*>(cws + r);
+    for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(cws + (size_t)z * nc + r);
+    *reinterpret_cast<f32x4*>(cvec + r) = s;
+  }
+}
 
 template <int SCHEME, int EX = kElemF32, bool RAW = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
@@ -462,11 +491,25 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
   // (kernel-argument struct indexed with a runtime index: copy the selected layer's fields through scalar selects)
   const void* X = a.l[0].X; const float* sbar = a.l[0].sbar; const float* xmax = a.l[0].xmax;
   float* C = a.l[0].C; float* cvec = a.l[0].cvec; int P = a.l[0].P;
+  int nsplit = a.l[0].nsplit, kchunk = a.l[0].kchunk; float* Cws = a.l[0].Cws; float* cws = a.l[0].cws;
 #pragma unroll
   for (int i = 1; i < kMaxGramLayers; ++i)
-    if (i == li) { X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P; }
-  if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
-  else gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, w - w0);
+    if (i == li) {
+      X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P;
+      nsplit = a.l[i].nsplit; kchunk = a.l[i].kchunk; Cws = a.l[i].Cws; cws = a.l[i].cws;
+    }
+  int wl = w - w0, kbeg = 0, kend = P;
+  if (nsplit > 1) {
+    const int per = a.M * (ntile * (ntile + 1) / 2);
+    const int z = wl / per;
+    wl -= z * per;
+    kbeg = z * kchunk;
+    kend = kbeg + kchunk < P ? kbeg + kchunk : P;
+    C = Cws + (size_t)z * a.M * B * B;
+    cvec = cws + (size_t)z * a.M * B;
+  }
+  if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
+  else gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1717,27 +1760,62 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* stream);
+                                  float* const* cvec, void* ws, size_t ws_bytes, void* stream);
+
+// Split-K plan of a multi-layer Gram launch: none while the unsplit grid already fills the GPU twice over (1024
+// workgroups); otherwise every layer is cut into pieces of about d* features, d* = total depth / 1024 (at least 1024),
+// at most 8 per layer.  Returns the workspace bytes (0: no split).
+static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, int* kchunk) {
+  const int ntile = B / 128;
+  const long long per = (long long)M * (ntile * (ntile + 1) / 2);
+  long long work = 0;
+  for (int i = 0; i < L; ++i) {
+    work += per * P[i];
+    nsplit[i] = 1;
+    kchunk[i] = P[i];
+  }
+  if (per * L >= 1024 || getenv("HECKA_GRAM_NOSPLIT")) return 0;
+  long long dstar = std::max<long long>(1024, work / 1024);
+  size_t bytes = 0;
+  for (int i = 0; i < L; ++i) {
+    long long ns = std::min<long long>(8, std::max<long long>(1, (P[i] + dstar / 2) / dstar));
+    const long long tiles16 = P[i] / 16;
+    long long kc = ((tiles16 + ns - 1) / ns) * 16;
+    ns = (P[i] + kc - 1) / kc;
+    nsplit[i] = (int)ns;
+    kchunk[i] = (int)kc;
+    if (ns > 1) bytes += (size_t)ns * ((size_t)M * B * B + (size_t)M * B) * sizeof(float);
+  }
+  return bytes;
+}
+
+size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P) {
+  if (L <= 0 || L > kMaxGramLayers || M <= 0 || B <= 0 || B % 128 != 0 || !P) return 0;
+  int ns[kMaxGramLayers], kc[kMaxGramLayers];
+  for (int i = 0; i < L; ++i)
+    if (P[i] <= 0 || P[i] % 16 != 0) return 0;
+  return gram_split_plan(L, M, B, P, ns, kc);
+}
 
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
                                 int B, const int* P, float* const* C, float* const* cvec, void* stream) {
   return gram_center_multi_impl(L, reinterpret_cast<const void* const*>(X), HECKA_DT_F32, sbar, xmax, M, B, P, C, cvec,
-                                stream);
+                                nullptr, 0, stream);
 }
 
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* stream) {
+                                float* const* cvec, void* ws, size_t ws_bytes, void* stream) {
   if (dtype != HECKA_DT_F32 && dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) {
     clear_error();
     return fail(HECKA_EINVAL, "gram_center_multi_x16: unknown dtype%s");
   }
-  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, stream);
+  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, stream);
 }
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* stream) {
+                                  float* const* cvec, void* ws, size_t ws_bytes, void* stream) {
   clear_error();
   const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
@@ -1748,6 +1826,16 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   bool have_max = xmax != nullptr;
   GramMultiArgs a;
   a.L = L;
+  a.M = M;
+  int nsp[kMaxGramLayers], kch[kMaxGramLayers];
+  for (int i = 0; i < L; ++i)
+    if (P[i] <= 0 || P[i] % 16 != 0) return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0 (P = %lld)%s", "", P[i]);
+  const size_t need = ws ? gram_split_plan(L, M, B, P, nsp, kch) : 0;   // no workspace given: no split
+  if (need > ws_bytes) return fail(HECKA_EWORKSPACE, "gram_center_multi: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  if (!need)
+    for (int i = 0; i < L; ++i) { nsp[i] = 1; kch[i] = P[i]; }
+  float* wsp = static_cast<float*>(ws);
+  bool any_split = false;
   long long wg = 0;
   for (int i = 0; i < L; ++i) {
     if (!X[i] || !sbar[i] || !C[i] || !cvec[i]) return fail(HECKA_EINVAL, "gram_center_multi: null layer pointer%s");
@@ -1755,8 +1843,16 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
       return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)%s", "", P[i]);
     if (i > 0 && P[i] > P[i - 1]) return fail(HECKA_EINVAL, "gram_center_multi: layers must come deepest (largest P) first%s");
     have_max = have_max && xmax[i] != nullptr;
-    wg += per;
-    a.l[i] = GramLayerArgs{X[i], sbar[i], xmax ? xmax[i] : nullptr, C[i], cvec[i], P[i], (int)wg};
+    wg += (long long)per * nsp[i];
+    float* Cws = nullptr;
+    float* cws = nullptr;
+    if (nsp[i] > 1) {
+      any_split = true;
+      Cws = wsp;
+      cws = wsp + (size_t)nsp[i] * M * B * B;
+      wsp = cws + (size_t)nsp[i] * M * B;
+    }
+    a.l[i] = GramLayerArgs{X[i], sbar[i], xmax ? xmax[i] : nullptr, C[i], cvec[i], P[i], (int)wg, nsp[i], kch[i], Cws, cws};
   }
   for (int i = L; i < kMaxGramLayers; ++i) a.l[i] = a.l[L - 1];
   if (wg > 0x7fffffffLL) return fail(HECKA_EINVAL, "gram_center_multi: grid too large%s");
@@ -1778,7 +1874,13 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
   else
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
-  return check_launch("gram_center_multi");
+  if (int rc = check_launch("gram_center_multi")) return rc;
+  if (any_split) {
+    const long long nC = (long long)M * B * B, nc = (long long)M * B;
+    hipLaunchKernelGGL(gram_split_reduce_kernel, dim3((unsigned)(((nC + nc) / 4 + 255) / 256), L), dim3(256), 0, st, a, nC, nc);
+    return check_launch("gram_center_multi (split reduce)");
+  }
+  return HECKA_OK;
 }
 
 size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {

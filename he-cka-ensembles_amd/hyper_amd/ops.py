@@ -163,10 +163,13 @@ def centered_gram_multi(Xs):
         out.append((C, cvec, xmax, sbar))
     n = len(Xs)
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
+    Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
+    nbytes = L.hecka_gram_center_multi_workspace_bytes(n, M, B, Ps)     # split-K slabs when the grid would be small
+    ws = torch.empty((nbytes // 4,), device=dev, dtype=torch.float32) if nbytes else None
     _lib.check(L.hecka_gram_center_multi_x16(
         n, ptrs([Xs[i] for i in order]), dt, ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
-        (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]), ptrs([out[i][0] for i in order]),
-        ptrs([out[i][1] for i in order]), st), 'gram_center_multi')
+        Ps, ptrs([out[i][0] for i in order]), ptrs([out[i][1] for i in order]),
+        _p(ws) if ws is not None else None, nbytes, st), 'gram_center_multi')
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
 
 

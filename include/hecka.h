@@ -250,9 +250,13 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
 #define HECKA_DT_BF16 1
 #define HECKA_DT_F16 2
 int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar, float* xmax, void* stream);
+/* ws: hecka_gram_center_multi_workspace_bytes(L, M, B, P) bytes (0 = none needed; NULL = never split).  With few
+ * workgroups over deep layers (small ensembles, a member shard of a multi-GPU run) the launch splits layers over K into
+ * partial Grams in ws and sums them in a fixed order - every stage of the epilogue is linear in the k range. */
+size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P);
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* stream);
+                                float* const* cvec, void* ws, size_t ws_bytes, void* stream);
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, int M, int B,
                        int P, void* dX, void* stream);
 

@@ -757,3 +757,45 @@ def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, monkeypatch):
         assert _relerr(res[mode][0].numpy(), yd.detach().numpy()) <= RTOL, mode
         assert _relerr(res[mode][1].numpy(), xd.grad.numpy()) <= RTOL, mode
         assert _relerr(res[mode][2].numpy(), Wd.grad.numpy()) <= RTOL, mode
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_multi_gram_split_k_matches_unsplit(dtype, monkeypatch):
+    """Few workgroups over deep layers (here 8 members x 1 tile x 3 layers): the multi-layer Gram launch splits layers
+    over K into partial Grams and sums them (hecka_gram_center_multi_workspace_bytes > 0).  Same C / cvec / loss / dX as
+    the unsplit launch (HECKA_GRAM_NOSPLIT=1) to fp32 rounding, and the oracle's loss and gradients at RTOL."""
+    import ctypes
+    from collections import OrderedDict
+    from oracle import hecka_ref as R
+    from hyper_amd import ops, _lib
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    dev = _dev()
+    dt = getattr(torch, dtype)
+    M, B, dims = 8, 128, (4096, 2048, 1024)
+    assert _lib.lib().hecka_gram_center_multi_workspace_bytes(3, M, B, (ctypes.c_int * 3)(*dims)) > 0
+    cfg = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+           'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031,
+                                feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': 'linear'})}
+    torch.manual_seed(31)
+    base = [(torch.relu(torch.randn(M, B, p)) + 0.1).to(dt) for p in dims]
+    res = {}
+    for split in ('1', '0'):
+        if split == '0':
+            monkeypatch.setenv('HECKA_GRAM_NOSPLIT', '1')
+        else:
+            monkeypatch.delenv('HECKA_GRAM_NOSPLIT', raising=False)
+        xs = [b.to(dev).requires_grad_(True) for b in base]
+        track = OrderedDict()
+        out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
+        out.backward()
+        res[split] = (out.item(), [x.grad.float().cpu() for x in xs], [t['gram'].cpu() for t in track['layer_track']])
+    assert abs(res['1'][0] - res['0'][0]) <= 2e-6 * abs(res['0'][0])
+    for a, b in zip(res['1'][2], res['0'][2]):
+        assert _relerr(a.numpy(), b.double().numpy()) <= 2e-6
+    tol = RTOL if dt == torch.float32 else 2.0 ** -8 * 1.01
+    xo = [b.double().requires_grad_(True) for b in base]
+    ref = R.run_config(cfg, xo)
+    ref.backward()
+    assert abs(res['1'][0] - ref.item()) <= (RTOL if dt == torch.float32 else 1e-4) * abs(ref.item())
+    for g, o in zip(res['1'][1], xo):
+        assert _relerr(g.numpy(), o.grad.numpy()) <= tol
