@@ -163,6 +163,10 @@ struct GemmTileX6 {
                  (unsigned)SB;
     const int ntiles = (kend - kbeg) / kX6BK;
     if (ntiles <= 0) return;
+    auto& smb = *[&]() {      // the planes the B fragments are read from
+      if constexpr (SAMEAB) return &sm.a;
+      else return &sm.b;
+    }();
 
     f32x4 ra[2][CA], rb[2][CB];  // two register sets: tiles t+1 and t+2 in flight
     auto gload_a = [&](auto SET, int kt) __attribute__((always_inline)) {
@@ -263,7 +267,8 @@ struct GemmTileX6 {
     // NSET) and the global loads of tile kt+3 spread one piece per MFMA gap (a piece = 10 VALU, three ds_write_b64
     // or the loads of one operand: about one 32-cycle MFMA).  FIRST: the local chain starts from zero.  GUARD: tail tiles, where
     // tile kt+1 / kt+3 may not exist; the steady-state instance has no branch inside.
-    static_assert(TM == 128 && TN == 128 && CA == 2 && CB == 2 && MI == 2 && NI == 2, "schedule written for the 128x128 tile");
+    static_assert(SCHEME == 1 || (TM == 128 && TN == 128), "the bf16x6 schedule is written for the 128x128 tile");
+    static_assert((TM == 128 || TM == 64) && TN == 128, "tile: 128 or 64 rows by 128 columns");
     auto iter = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(NSET)::value;
       constexpr bool G = decltype(GUARD)::value;
@@ -284,7 +289,7 @@ struct GemmTileX6 {
       auto ldb_ = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          fb[j][p] = *reinterpret_cast<const bf16x8*>(&(SAMEAB ? sm.a : sm.b)[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+          fb[j][p] = *reinterpret_cast<const bf16x8*>(&smb[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
       };
       lda_(2);
       ldb_(0);
@@ -333,11 +338,15 @@ struct GemmTileX6 {
       }
       __syncthreads();
     };
-    // f16x3 k-tile: 12 MFMAs (hh, hl, lh on the four 32x32 tiles); all four fragment groups are read at the top;
-    // gaps: 0 A q0 split | 1 A q0 write | 2 A q1 split | 3 A q1 write | 4 A loads | 5-8 B likewise | 9 B loads
+    // f16x3 k-tile: 3 MI NI MFMAs (hh, hl, lh on the wave's 32x32 tiles; 12 for the 128x128 tile); all fragment groups are
+    // read at the top; the staging work of the next tile goes one item per MFMA gap, in this order:
+    //   A quads (split, write each) | A loads | B quads (split, write each) | B loads
+    // (128x128: gaps 0-3 A, 4 A loads, 5-8 B, 9 B loads; a 64-row tile has 6 MFMAs and 8 items - the last two follow
+    // the last MFMA)
     auto iter16 = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(NSET)::value;
       constexpr bool G = decltype(GUARD)::value;
+      constexpr int NM = 3 * MI * NI, NITEMS = 2 * CA + 1 + 2 * CB + 1;
       const int st = kt & 1;
       const bool more = !G || kt + 1 < ntiles;
       const bool load = !G || kt + 3 < ntiles;
@@ -352,7 +361,7 @@ struct GemmTileX6 {
         if (p == 0 || BLOW) {
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            fb[j][p] = *reinterpret_cast<const f16x8*>(&(SAMEAB ? sm.a : sm.b)[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+            fb[j][p] = *reinterpret_cast<const f16x8*>(&smb[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -360,26 +369,28 @@ struct GemmTileX6 {
       constexpr int PB[3] = {0, 1, 0};
       u32x2 qv[2];
 #pragma unroll
-      for (int n = 0; n < 12; ++n) {
-        const int e = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        if (e == 0 || (e == 1 && BLOW) || (e == 2 && ALOW)) {   // e = 1 is A.h x B.l, e = 2 is A.l x B.h
-          if (FOLD) {
-            f32x16 c = loc[i][j];
-            if (decltype(FIRST)::value && e == 0) {
+      for (int n = 0; n < (NM > NITEMS ? NM : NITEMS); ++n) {
+        if (n < NM) {
+          const int e = n / (MI * NI), i = (n % (MI * NI)) / NI, j = n % NI;
+          if (e == 0 || (e == 1 && BLOW) || (e == 2 && ALOW)) {   // e = 1 is A.h x B.l, e = 2 is A.l x B.h
+            if (FOLD) {
+              f32x16 c = loc[i][j];
+              if (decltype(FIRST)::value && e == 0) {
 #pragma unroll
-              for (int q = 0; q < 16; ++q) c[q] = 0.f;
+                for (int q = 0; q < 16; ++q) c[q] = 0.f;
+              }
+              loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], acc[i][j], 0, 0, 0);
             }
-            loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], c, 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[e]], fb[j][PB[e]], acc[i][j], 0, 0, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n == 4) { if (load) gload_a(NSET, kt + 3); }
-        else if (n == 9) { if (load) gload_b(NSET, kt + 3); }
-        else if (n < 9) {
-          const bool isA = n < 4;
-          const int r = isA ? n : n - 5, quad = r >> 1, step = r & 1;
+        if (n == 2 * CA) { if (load) gload_a(NSET, kt + 3); }
+        else if (n == 2 * CA + 1 + 2 * CB) { if (load) gload_b(NSET, kt + 3); }
+        else if (n < NITEMS) {
+          const bool isA = n < 2 * CA;
+          const int r = isA ? n : n - (2 * CA + 1), quad = r >> 1, step = r & 1;
           f32x4& src = isA ? ra[S][quad] : rb[S][quad];
           if (more && (isA || !SAMEAB)) {
             if (step == 0) {

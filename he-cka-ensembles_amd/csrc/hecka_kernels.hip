@@ -932,7 +932,7 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(con
 // General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
 // fp16 range by powers of two from per-batch maxima (upper bounds are fine), optional split-K (blockIdx.y: partial
 // slabs for a fixed-order second stage).  The convolution GEMMs of the batched-weight layers at 128 and more channels.
-template <bool NN, bool FOLD>
+template <bool NN, bool FOLD, int TM = 128>
 __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                                   float* __restrict__ C, int rows, int cols, int K,
                                                                   long long strideA, long long strideB,
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const 
                                                                   const float* __restrict__ amaxB, int amaxB_stride,
                                                                   float alpha, int tilesM, int tilesN, int kchunk,
                                                                   long long slab) {
-  using Tile = GemmTileX6<128, 128, NN, ScaleProX6<1>, 1, FOLD>;
+  using Tile = GemmTileX6<TM, 128, NN, ScaleProX6<1>, 1, FOLD>;   // TM = 64: the 64-channel stages (rows = 64 or 576)
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
@@ -954,9 +954,9 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const 
   const float unscale = (gridDim.y > 1 ? 1.0f : alpha) / (pro.sa * pro.sb);
   Tile tile;
   tile.run(sm, A + (size_t)b * strideA, (unsigned)((size_t)rows * K * 4u), K, Bm + (size_t)b * strideB,
-           (unsigned)((size_t)cols * K * 4u), NN ? cols : K, ti * 128, tj * 128, kbeg, kend, pro);
+           (unsigned)((size_t)cols * K * 4u), NN ? cols : K, ti * TM, tj * 128, kbeg, kend, pro);
   float* out = C + (size_t)blockIdx.y * slab + (size_t)b * rows * cols;
-  tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * 128 + lr) * cols + tj * 128 + lc] = v * unscale; });
+  tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * TM + lr) * cols + tj * 128 + lc] = v * unscale; });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2276,7 +2276,7 @@ int hecka_absmax_rows_f32(const float* V, int rows, long long n, float* out, voi
 }
 
 static int bgemm_x3_nsplit(int batch, int rows, int cols, int K) {
-  const long long tiles = (long long)(rows / 128) * (cols / 128) * batch;
+  const long long tiles = (long long)(rows / (rows % 128 ? 64 : 128)) * (cols / 128) * batch;
   if (tiles >= 512 || K < 2048) return 1;
   long long want = (1024 + tiles - 1) / tiles, maxs = K / 1024;
   if (want > maxs) want = maxs;
@@ -2284,9 +2284,9 @@ static int bgemm_x3_nsplit(int batch, int rows, int cols, int K) {
 }
 
 int hecka_bgemm_x3_eligible(int batch, int rows, int cols, int K) {
-  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && cols > 0 && K > 0 && rows % 128 == 0 && cols % 128 == 0 &&
+  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && cols > 0 && K > 0 && rows % 64 == 0 && cols % 128 == 0 &&
          K % kX6BK == 0 && (long long)rows * K < (1ll << 30) && (long long)cols * K < (1ll << 30) &&
-         (long long)batch * (rows / 128) * (cols / 128) < (1ll << 31);
+         (long long)batch * (rows / 64) * (cols / 128) < (1ll << 31);
 }
 
 size_t hecka_bgemm_x3_workspace_bytes(int batch, int rows, int cols, int K) {
@@ -2302,11 +2302,12 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
   if (!A || !Bm || !C || !amaxA || !amaxB) return fail(HECKA_EINVAL, "bgemm_x3: null pointer%s");
   if (!hecka_bgemm_x3_eligible(batch, rows, cols, K) || !aligned16(A) || !aligned16(Bm) || !aligned16(C) ||
       (strideA % 4) || (strideB % 4))
-    return fail(HECKA_EINVAL, "bgemm_x3: needs HECKA_GEMM_AUTO, rows %% 128 == 0, cols %% 128 == 0, K %% 16 == 0, 16-byte alignment%s");
+    return fail(HECKA_EINVAL, "bgemm_x3: needs HECKA_GEMM_AUTO, rows %% 64 == 0, cols %% 128 == 0, K %% 16 == 0, 16-byte alignment%s");
   const int ns = bgemm_x3_nsplit(batch, rows, cols, K);
   const size_t need = ns > 1 ? (size_t)ns * batch * rows * cols * sizeof(float) : 0;
   if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "bgemm_x3: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
-  const int tilesM = rows / 128, tilesN = cols / 128;
+  const int tm = rows % 128 ? 64 : 128;
+  const int tilesM = rows / tm, tilesN = cols / 128;
   const long long ktiles = K / kX6BK;
   const int kchunk = (int)(((ktiles + ns - 1) / ns) * kX6BK);
   const bool fold = kchunk > 1024;
@@ -2315,8 +2316,14 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
   float* out = ns > 1 ? (float*)ws : C;
   const long long slab = (long long)batch * rows * cols;
 #define HECKA_BX3(NNV, FOLDV) \
-  hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, strideB, \
-                     amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab)
+  do { \
+    if (tm == 128) \
+      hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV, 128>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, \
+                         strideB, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab); \
+    else \
+      hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV, 64>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, \
+                         strideB, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab); \
+  } while (0)
   if (nn) { if (fold) HECKA_BX3(true, true); else HECKA_BX3(true, false); }
   else { if (fold) HECKA_BX3(false, true); else HECKA_BX3(false, false); }
 #undef HECKA_BX3

@@ -201,7 +201,7 @@ int hecka_bgemm_splitk_f32(const float* A, const float* B, float* C, int batch, 
                            long long strideA, long long strideB, int nn, float alpha, void* ws, size_t ws_bytes,
                            void* stream);
 
-/* hecka_bgemm_f32 (no bias) on the fp16-split tile, 2.5-3x the fp32-MFMA rate, for interior shapes (rows % 128 == 0,
+/* hecka_bgemm_f32 (no bias) on the fp16-split tile, 2.5-3x the fp32-MFMA rate, for interior shapes (rows % 64 == 0,
  * cols % 128 == 0, K % 16 == 0; hecka_bgemm_x3_eligible): amaxA [batch] and amaxB [batch, or one value with
  * amaxB_stride = 0 for a shared operand] are max |A[b]| / max |B[b]| or upper bounds (hecka_absmax_rows_f32: out[r] =
  * max |V[r, 0..n)|).  Few tiles over a long K (convolution weight gradients) are split over K:

@@ -727,17 +727,18 @@ def test_graphed_train_step_equals_eager():
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-12)
 
 
-@pytest.mark.parametrize('N,HW,shared', [(8, 8, False), (64, 16, True)])
-def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, monkeypatch):
+@pytest.mark.parametrize('N,HW,shared,C', [(8, 8, False, 128), (64, 16, True, 128), (16, 16, False, 64)])
+def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, C, monkeypatch):
     """Conv2d at 128 channels (interior shapes, no bias): forward, weight gradient (split-K in the second case) and
     input gradient on the fp16-split batched GEMM (hecka_bgemm_x3_f32) against F.conv2d per member in fp64, and
-    against the fp32-MFMA route (HECKA_CONV_X3=0)."""
+    against the fp32-MFMA route (HECKA_CONV_X3=0).  C = 64: the 64-row tile (forward rows = 64, dgrad rows = 576; the
+    weight gradient's 576 columns stay on the fp32 split-K kernel)."""
     import torch.nn.functional as F
     from hyper_amd.layers.conv import BatchedConv2d
     from hyper_amd import _lib
     dev = _dev()
     torch.manual_seed(11)
-    M, C, O = 2, 128, 128
+    M, O = 2, C
     x = torch.randn((N, C, HW, HW) if shared else (M, N, C, HW, HW), device=dev)
     W = torch.randn(M, O, C, 3, 3, device=dev) * 0.05
     up = torch.randn(M, N, O, HW, HW, device=dev)
