@@ -245,6 +245,10 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
 // Split-precision variants of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands
 // split on the way into LDS (gemm_bf16x6.hpp).  SCHEME 0: three bf16 terms.  SCHEME 1: two fp16 terms of the centred
 // value scaled by s = 2^k, k from xmax[m] so that |x - sbar| * s <= 2 xmax s <= 2^14; the epilogue undoes s^2.
+#ifndef HECKA_DIAG_TILES
+#define HECKA_DIAG_TILES 1
+#endif
+
 template <int SCHEME>
 struct CenterProX6 {
   const float* sbar;
@@ -326,7 +330,7 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = pro.ssv = f32x4{0.f, 0.f, 0.f, 0.f};
   const float unscale = 1.0f / (pro.s * pro.s);
   Tile tile;
-  if (I == J) {
+  if (HECKA_DIAG_TILES && I == J) {
     TileD td;
     td.run(sm, Xm, (unsigned)B * P * 2u, P, Xm, (unsigned)B * P * 2u, P, I * 128, J * 128, kbeg, kend, pro);
 #pragma unroll
@@ -390,7 +394,7 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float unscale = SCHEME == 1 ? 1.0f / (pro.s * pro.s) : 1.0f;
   Tile tile;
-  if (I == J) {
+  if (HECKA_DIAG_TILES && I == J) {
     TileD td;
     td.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, kbeg, kend, pro);
 #pragma unroll
