@@ -52,7 +52,7 @@ def test_combine_slice_equals_full_combine(M, B):
 
 def _case(name):
     torch.manual_seed(17)
-    M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9))}[name]
+    M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9)), 'm64b512': (64, 512, (2048, 256))}[name]
     feats = [torch.randn(M, B, p) * (1.0 + 0.5 * i) for i, p in enumerate(Ps)]
     cfg = {'name': 'model_layers', 'reduction': 'mean',
            'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031,
@@ -81,7 +81,8 @@ def _worker(rank, world, port, name, out, mode):
 
 
 @pytest.mark.parametrize('name,world,mode', [('m64', 2, 'slice'), ('m64', 4, 'slice'), ('m12', 3, 'slice'),
-                                             ('m64', 2, 'gather')])
+                                             ('m64', 2, 'gather'), ('m64b512', 8, 'slice')])   # the last: the bench's
+# member / sample counts at the driver's largest world size (8 members per rank, 32768-column slices, split-K Grams)
 def test_ranks_on_one_card_match_unsharded(name, world, mode, tmp_path):
     import torch.multiprocessing as mp
     from hyper_amd.diversity.model_kernels import build_model_kernel
