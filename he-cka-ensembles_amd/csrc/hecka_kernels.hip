@@ -1564,7 +1564,8 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ run_mean, const float* __restrict__ run_var,
                                                                 int training, float eps, float* __restrict__ y,
                                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                                float* __restrict__ batch_var) {
+                                                                float* __restrict__ batch_var,
+                                                                const float* __restrict__ res, int relu) {
   __shared__ double red[4];
   const int c = blockIdx.x, g = blockIdx.y;
   const long long cnt = (long long)N * S;
@@ -1607,6 +1608,11 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
       f32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = fmaf(v[e], sc, sh);
+      if (res) r += *reinterpret_cast<const f32x4*>(res + o + 4 * q);      // fused residual add and relu
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+      }
       *reinterpret_cast<f32x4*>(y + o + 4 * q) = r;
     }
   }
@@ -1616,7 +1622,10 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                                 const float* __restrict__ weight, int N, int C, long long S,
                                                                 int training, float* __restrict__ dx, float* __restrict__ dweight,
-                                                                float* __restrict__ dbias) {
+                                                                float* __restrict__ dbias, const float* __restrict__ yout,
+                                                                float* __restrict__ dres) {
+  // yout (the fused op's output; may be NULL): relu mask, the gradient reaching the normalisation is dy where yout > 0;
+  // dres (may be NULL) receives that masked gradient for the residual branch
   __shared__ double red[4];
   const int c = blockIdx.x, g = blockIdx.y;
   const long long cnt = (long long)N * S;
@@ -1627,8 +1636,14 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   for (int n = m.ni; n < N; n += m.ipp) {
     const size_t o = base + (size_t)n * nstride;
     for (int q = m.si; q < m.s4; q += m.tpi) {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + o + 4 * q);
+      if (yout) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(yout + o + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
+        if (dres) *reinterpret_cast<f32x4*>(dres + o + 4 * q) = d;
+      }
       a1 += d;
 #pragma unroll
       for (int e = 0; e < 4; ++e) a2[e] = fmaf(d[e], (v[e] - mean) * rstd, a2[e]);
@@ -1646,8 +1661,13 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   for (int n = m.ni; n < N; n += m.ipp) {
     const size_t o = base + (size_t)n * nstride;
     for (int q = m.si; q < m.s4; q += m.tpi) {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + o + 4 * q);
+      if (yout) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(yout + o + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
+      }
       f32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = k * (d[e] - m1 - (v[e] - mean) * rstd * m2);
@@ -2400,7 +2420,7 @@ int hecka_batchnorm_fwd_f32(const float* x, int G, int N, int C, long long S, co
   if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_fwd: eval mode needs running statistics%s");
   if (S % 4 == 0 && aligned16(x) && aligned16(y) && !getenv("HECKA_BN_SCALAR"))
     hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
-                       run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var);
+                       run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, (const float*)nullptr, 0);
   else
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                        run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var);
@@ -2415,11 +2435,39 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_bwd: size out of range%s");
   if (S % 4 == 0 && aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)) && !getenv("HECKA_BN_SCALAR"))
     hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                       weight, N, C, S, training, dx, dweight, dbias);
+                       weight, N, C, S, training, dx, dweight, dbias, (const float*)nullptr, (float*)nullptr);
   else
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
                        weight, N, C, S, training, dx, dweight, dbias);
   return check_launch("batchnorm_bwd");
+}
+
+int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
+                                const float* bias, const float* run_mean, const float* run_var, int training, float eps,
+                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, void* stream) {
+  clear_error();
+  if (!x || !y || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_fwd: null pointer%s");
+  if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_fwd: size out of range%s");
+  if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_act_fwd: eval mode needs running statistics%s");
+  if (S % 4 != 0 || !aligned16(x) || !aligned16(y) || (res && !aligned16(res)))
+    return fail(HECKA_EINVAL, "batchnorm_act_fwd: needs S %% 4 == 0 and 16-byte alignment%s");
+  hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
+                     run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, res, relu);
+  return check_launch("batchnorm_act_fwd");
+}
+
+int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y, const float* save_mean,
+                                const float* save_rstd, const float* weight, int G, int N, int C, long long S,
+                                int training, float* dx, float* dres, float* dweight, float* dbias, void* stream) {
+  clear_error();
+  if (!dy || !x || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_bwd: null pointer%s");
+  if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_bwd: size out of range%s");
+  if (dres && !y) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dres needs the forward output y%s");
+  if (S % 4 != 0 || !aligned16(x) || !aligned16(dy) || (y && !aligned16(y)) || (dx && !aligned16(dx)) || (dres && !aligned16(dres)))
+    return fail(HECKA_EINVAL, "batchnorm_act_bwd: needs S %% 4 == 0 and 16-byte alignment%s");
+  hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
+                     weight, N, C, S, training, dx, dweight, dbias, y, dres);
+  return check_launch("batchnorm_act_bwd");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,

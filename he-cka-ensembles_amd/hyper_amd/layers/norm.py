@@ -78,6 +78,63 @@ class BatchedBatchNorm(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class BatchedBatchNormAct(torch.autograd.Function):
+    """y[m] = [relu](batch_norm(x[m], weight[m], bias[m]) [+ res[m]]) in one launch each way (hecka_batchnorm_act_*): the
+    two tails of a ResNet block, norm -> relu and norm -> + shortcut -> relu.  Same by-products as BatchedBatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, run_mean, run_var, training, eps, relu):
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError('hyper_amd BatchNorm needs fp32 GPU tensors; there is no CPU path')
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        M, N, C = x.shape[:3]
+        S = int(x[0, 0, 0].numel())
+        w = weight.contiguous() if weight is not None else None
+        b = bias.contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        mean = torch.empty((M, C), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        var = torch.empty_like(mean) if training else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(_lib.lib().hecka_batchnorm_act_fwd_f32(
+            x.data_ptr(), ptr(res), M, N, C, S, ptr(w), ptr(b), ptr(run_mean), ptr(run_var), int(training), float(eps),
+            int(bool(relu)), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var),
+            torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
+        ctx.save_for_backward(x, mean, rstd, w, y if relu else None)
+        ctx.cfg = (training, S, weight is not None, bias is not None, res is not None)
+        if var is None:
+            var = mean.new_zeros(())
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, rstd, w, y = ctx.saved_tensors
+        training, S, has_w, has_b, has_res = ctx.cfg
+        M, N, C = x.shape[:3]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dres = None
+        if has_res and ctx.needs_input_grad[1]:
+            dres = torch.empty_like(x) if y is not None else dy      # no relu: the residual's gradient is dy itself
+        dw = torch.empty_like(mean) if has_w and ctx.needs_input_grad[2] else None
+        db = torch.empty_like(mean) if has_b and ctx.needs_input_grad[3] else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(_lib.lib().hecka_batchnorm_act_bwd_f32(
+            dy.data_ptr(), x.data_ptr(), ptr(y), mean.data_ptr(), rstd.data_ptr(), ptr(w), M, N, C, S, int(training),
+            ptr(dx), ptr(dres) if y is not None else None, ptr(dw), ptr(db), torch.cuda.current_stream().cuda_stream),
+            'batchnorm_act_bwd')
+        return dx, dres, dw, db, None, None, None, None, None
+
+
+def fused_act_eligible(x):
+    """The fused norm (+ residual) + relu launch takes fp32 GPU tensors with a multiple of four positions per channel."""
+    import os
+    return (os.environ.get('HECKA_BN_FUSE', '1') != '0' and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
+            and int(x[0, 0, 0].numel()) % 4 == 0)
+
+
 class _NormBase(GenModule):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, track=True):
         super().__init__(track=track)
@@ -106,8 +163,11 @@ class _NormBase(GenModule):
 
 
 class _BatchNorm(_NormBase):
-    def forward(self, params, input):
+    def forward(self, params, input, residual=None, relu=False):
+        """`residual` / `relu` (not in the reference's signature): y = [relu](norm(input) [+ residual]) as ONE launch when
+        the shape allows (fused_act_eligible), else the same thing with torch ops behind the plain norm."""
         self._check_input_dim(input)
+        fused = (relu or residual is not None) and fused_act_eligible(input)
         weight = bias = None
         if self.affine:
             viewed = self.affine_module.from_flat(params['affine']['self'])
@@ -117,7 +177,15 @@ class _BatchNorm(_NormBase):
         run_mean = run_var = None
         if bufs is not None and not bn_training:
             run_mean, run_var = bufs.gather('mean'), bufs.gather('var')
-        y, mean, var = BatchedBatchNorm.apply(input, weight, bias, run_mean, run_var, bn_training, self.eps)
+        if fused:
+            y, mean, var = BatchedBatchNormAct.apply(input, residual, weight, bias, run_mean, run_var, bn_training,
+                                                     self.eps, bool(relu))
+        else:
+            y, mean, var = BatchedBatchNorm.apply(input, weight, bias, run_mean, run_var, bn_training, self.eps)
+            if residual is not None:
+                y = y + residual
+            if relu:
+                y = torch.relu(y)
         if self.training and bufs is not None:
             cnt = input.shape[1] * int(input[0, 0, 0].numel())
             with torch.no_grad():

@@ -45,10 +45,16 @@ class BasicBlock(GenModule):
 
     def forward(self, params, x):
         feat = OrderedDict()
-        out = self.act(None, self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1])[1])[1]
-        out = self.norm2(params['norm2'], self.conv2(params['conv2'], out)[1])[1]
-        out = out + (self.shortcut(params['shortcut'], x)[1] if self.use_short else x)
-        out = self.act(None, out)[1]
+        if self.act._name == 'relu' and hasattr(self.norm1, 'affine_module'):
+            # norm -> relu and norm -> + shortcut -> relu as one launch each (layers/norm.py: BatchedBatchNormAct)
+            out = self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1], relu=True)[1]
+            short = self.shortcut(params['shortcut'], x)[1] if self.use_short else x
+            out = self.norm2(params['norm2'], self.conv2(params['conv2'], out)[1], residual=short, relu=True)[1]
+        else:
+            out = self.act(None, self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1])[1])[1]
+            out = self.norm2(params['norm2'], self.conv2(params['conv2'], out)[1])[1]
+            out = out + (self.shortcut(params['shortcut'], x)[1] if self.use_short else x)
+            out = self.act(None, out)[1]
         if self._track:
             feat['block'] = out
         return feat, out
@@ -100,7 +106,10 @@ class ResNet(GenModule):
 
     def forward(self, params, x):
         feat = OrderedDict()
-        feat['conv1'] = out = self.act(None, self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1])[1])[1]
+        if self.act._name == 'relu' and hasattr(self.norm1, 'affine_module'):
+            feat['conv1'] = out = self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1], relu=True)[1]
+        else:
+            feat['conv1'] = out = self.act(None, self.norm1(params['norm1'], self.conv1(params['conv1'], x)[1])[1])[1]
         for name in ('layer1', 'layer2', 'layer3', 'layer4'):
             feat[name], out = getattr(self, name)(params[name], out)
         M, N = out.shape[:2]       # global average pooling

@@ -238,6 +238,16 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
                             const float* weight, int G, int N, int C, long long S, int training, float* dx,
                             float* dweight, float* dbias, void* stream);
 
+/* Batched BatchNorm fused with what follows it in a ResNet block (hyper/target/resnet.py:67-74: norm -> relu, and
+ * norm -> + shortcut -> relu): y = [relu](batch_norm(x) [+ res]).  Backward takes the forward OUTPUT y as the relu mask
+ * (NULL: no relu) and returns the masked gradient for the residual branch in dres (may be NULL).  S % 4 == 0. */
+int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
+                                const float* bias, const float* run_mean, const float* run_var, int training, float eps,
+                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, void* stream);
+int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y, const float* save_mean,
+                                const float* save_rstd, const float* weight, int G, int N, int C, long long S,
+                                int training, float* dx, float* dres, float* dweight, float* dbias, void* stream);
+
 /* ---- 16-bit features (BASELINE config 3: bf16 networks) ------------------------------------------------------------
  * The reference runs the same Python path on bf16 feature tensors (torch.bmm in bf16, hyper/diversity/kernels.py:122);
  * here the three kernels that touch X read bf16 / fp16 features as they lie in HBM (half the bytes, no up-cast pass),

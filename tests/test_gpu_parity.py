@@ -800,3 +800,30 @@ def test_multi_gram_split_k_matches_unsplit(dtype, monkeypatch):
     assert abs(res['1'][0] - ref.item()) <= (RTOL if dt == torch.float32 else 1e-4) * abs(ref.item())
     for g, o in zip(res['1'][1], xo):
         assert _relerr(g.numpy(), o.grad.numpy()) <= tol
+
+
+@pytest.mark.parametrize('with_res', [False, True])
+def test_fused_batchnorm_relu_matches_unfused(with_res, monkeypatch):
+    """BatchNorm2d(..., residual=, relu=True) as one launch each way against the plain norm + torch add / relu
+    (HECKA_BN_FUSE=0): output, dx, d residual, d affine - and the same running statistics."""
+    from hyper_amd.layers.norm import BatchedBatchNorm, BatchedBatchNormAct
+    dev = _dev()
+    torch.manual_seed(3)
+    M, N, C, H = 3, 6, 8, 4
+    x0 = torch.randn(M, N, C, H, H, device=dev)
+    r0 = torch.randn(M, N, C, H, H, device=dev)
+    w0, b0 = torch.rand(M, C, device=dev) + 0.5, torch.randn(M, C, device=dev) * 0.1
+    up = torch.randn(M, N, C, H, H, device=dev)
+    outs = []
+    for fused in (True, False):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        if fused:
+            y, mean, var = BatchedBatchNormAct.apply(x, r if with_res else None, w, b, None, None, True, 1e-5, True)
+        else:
+            y, mean, var = BatchedBatchNorm.apply(x, w, b, None, None, True, 1e-5)
+            y = torch.relu(y + r if with_res else y)
+        (y * up).sum().backward()
+        outs.append([y.detach(), x.grad, w.grad, b.grad, mean, var] + ([r.grad] if with_res else []))
+    for a, b_ in zip(*outs):
+        assert _relerr(a.cpu().numpy(), b_.cpu().double().numpy()) <= 2e-6
