@@ -107,6 +107,14 @@ __device__ __forceinline__ void split2(const f32x4& v, int q0, V& vh, V& vm, V& 
   vl[qo] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
 }
 
+// A prologue may supply the NN operand IMPLICITLY (Pro::kImplicitB = true): instead of row k of a [K, cols] matrix the
+// tile asks pro.bvoff(k) for the byte offset of element (k, this thread's column) in the buffer rsB is made over - an
+// out-of-range offset reads as zero (buffer bounds check).  The convolution kernels gather image patches this way.
+template <class P, class = void>
+struct implicit_b : std::false_type {};
+template <class P>
+struct implicit_b<P, std::void_t<decltype(P::kImplicitB)>> : std::bool_constant<P::kImplicitB> {};
+
 // Product tile out[i,j] = sum_k A[i,k] B(k,j), interior tiles only (rows/cols multiples of the tile, (kend - kbeg) a
 // multiple of 16, 16-byte aligned A rows).  A is [rows, K] (k contiguous).  NN = false: B is [cols, K] (k contiguous,
 // 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
@@ -192,6 +200,11 @@ struct GemmTileX6 {
         if (NN) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
+            if constexpr (implicit_b<Pro>::value) {
+              const int k = __builtin_amdgcn_readfirstlane(kbeg + kt * kX6BK + 8 * (t >> 7) + 4 * i + c);   // wave-uniform
+              rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)pro.bvoff(k), 0, 0));
+              continue;
+            }
             const int so = (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * (unsigned)SB);
             if (EB == kElemF32)
               rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)bgoff[i], so, 0));

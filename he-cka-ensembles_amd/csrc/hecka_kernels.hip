@@ -963,6 +963,81 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const 
   tile.for_each([&](int lr, int lc, float v) { out[(size_t)(ti * TM + lr) * cols + tj * 128 + lc] = v * unscale; });
 }
 
+// Implicit-GEMM convolution on the fp16-split tile (unit stride and dilation, output as large as the input):
+//   Y[b][n][r][h][w] = alpha * sum_k A[b][r][k] * X[b][n][c(k)][h + di(k)][w + dj(k)]      (zero outside the image)
+// The B operand is never materialised: the tile's transposing loader asks ConvProX3::bvoff(k) for the address of tap k at
+// the thread's pixel - a per-tap table (element offset, di, dj; wave-uniform, read with scalar loads) plus the pixel's
+// base index, out of range -> a buffer offset that reads as zero.  The epilogue writes NCHW directly.  Forward:
+// A = weights [O, C kh kw], X = the layer input.  Input gradient: A = the rotated weights [C, O kh kw], X = dy - no
+// patch matrix, no col2im.
+struct ConvProX3 {
+  static constexpr bool kImplicitB = true;
+  float sa, sb;
+  const int2* tab;
+  int base, h, w, H, W;
+  template <class S> __device__ __forceinline__ void prefetch(S, int) {}
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sa;
+  }
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sb;
+  }
+  __device__ __forceinline__ unsigned bvoff(int k) const {
+    const int2 e = tab[k];
+    const int di = e.y >> 16, dj = (int)(short)(e.y & 0xffff);
+    const bool ok = (unsigned)(h + di) < (unsigned)H && (unsigned)(w + dj) < (unsigned)W;
+    return ok ? (unsigned)(base + e.x) * 4u : 0xFFFFFFF0u;
+  }
+};
+
+template <bool FOLD, int TM>
+__global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const float* __restrict__ A, const float* __restrict__ X,
+                                                                 float* __restrict__ Y, const int2* __restrict__ tab,
+                                                                 int rows, int K, long long strideA, long long strideX,
+                                                                 int N, int Cin, int H, int W,
+                                                                 const float* __restrict__ amaxA,
+                                                                 const float* __restrict__ amaxB, int amaxB_stride,
+                                                                 float alpha, int tilesM, int tilesN) {
+  using Tile = GemmTileX6<TM, 128, true, ConvProX3, 1, FOLD>;
+  __shared__ typename Tile::Smem sm;
+  const int per = tilesM * tilesN;
+  const int b = blockIdx.x / per, tl = blockIdx.x % per;
+  const int ti = tl % tilesM, tj = tl / tilesM;
+  const int S = H * W, Q = N * S;
+  ConvProX3 pro;
+  pro.sa = pow2_scale(amaxA[b], 14);
+  pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
+  pro.tab = tab;
+  pro.H = H;
+  pro.W = W;
+  {
+    const int q = tj * 128 + (threadIdx.x & 127);      // the pixel whose taps this thread gathers
+    const int n = q / S, rem = q - n * S;
+    pro.h = rem / W;
+    pro.w = rem - pro.h * W;
+    pro.base = (n * Cin * H + pro.h) * W + pro.w;
+  }
+  const float unscale = alpha / (pro.sa * pro.sb);
+  Tile tile;
+  tile.run(sm, A + (size_t)b * strideA, (unsigned)((size_t)rows * K * 4u), K, X + (size_t)b * strideX,
+           (unsigned)((size_t)N * Cin * S * 4u), Q, ti * TM, tj * 128, 0, K, pro);
+  // NCHW epilogue: this lane's two output pixels (one per 32-column block of the wave's 64 columns)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  size_t obase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = tj * 128 + (wave & 1) * 64 + j * 32 + (lane & 31);
+    const int n = q / S;
+    obase[j] = (size_t)n * rows * S + (size_t)(q - n * S);
+  }
+  float* out = Y + (size_t)b * N * rows * S;
+  tile.for_each([&](int lr, int lc, float v) {
+    out[obase[(lc >> 5) & 1] + (size_t)(ti * TM + lr) * S] = v * unscale;
+  });
+}
+
 // ------------------------------------------------------------------------------------------
 // (7) row-wise helpers for the un-fused functional API (center_gram and its backward).
 //     HBM-bound elementwise passes over [rows, cols].
@@ -2359,6 +2434,37 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
     return check_launch("bgemm_x3 (reduce)");
   }
   return HECKA_OK;
+}
+
+int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, int W) {
+  const long long S = (long long)H * W, Q = (long long)N * S;
+  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && K > 0 && N > 0 && Cin > 0 && H > 0 && W > 0 &&
+         rows % 64 == 0 && Q % 128 == 0 && K % kX6BK == 0 && (long long)rows * K < (1ll << 30) &&
+         (long long)N * Cin * S < (1ll << 30) && (long long)N * rows * S < (1ll << 31) &&
+         (long long)batch * (rows / 64) * (Q / 128) < (1ll << 31);
+}
+
+int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                      long long strideA, long long strideX, int N, int Cin, int H, int W, float alpha, const float* amaxA,
+                      const float* amaxB, int amaxB_stride, void* stream) {
+  clear_error();
+  if (!A || !X || !Y || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_x3: null pointer%s");
+  if (!hecka_conv_x3_eligible(batch, rows, K, N, Cin, H, W) || !aligned16(A) || (strideA % 4) ||
+      (reinterpret_cast<uintptr_t>(tab) & 7))
+    return fail(HECKA_EINVAL, "conv_x3: needs HECKA_GEMM_AUTO, rows %% 64 == 0, N H W %% 128 == 0, K %% 16 == 0%s");
+  const int tm = rows % 128 ? 64 : 128;
+  const int tilesM = rows / tm, tilesN = (int)((long long)N * H * W / 128);
+  dim3 grid((unsigned)((long long)batch * tilesM * tilesN));
+  hipStream_t st = (hipStream_t)stream;
+  const int2* t2 = reinterpret_cast<const int2*>(tab);
+  const bool fold = K > 1024;
+#define HECKA_CX3(FOLDV, TMV) \
+  hipLaunchKernelGGL((conv_x3_kernel<FOLDV, TMV>), grid, dim3(kThreads), 0, st, A, X, Y, t2, rows, K, strideA, strideX, N, Cin, H, \
+                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN)
+  if (tm == 128) { if (fold) HECKA_CX3(true, 128); else HECKA_CX3(false, 128); }
+  else { if (fold) HECKA_CX3(true, 64); else HECKA_CX3(false, 64); }
+#undef HECKA_CX3
+  return check_launch("conv_x3");
 }
 
 static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,

@@ -46,6 +46,40 @@ def _col2im(dcols, M, N, C, H, W, geom):
     return dx
 
 
+_TABS = {}
+
+
+def _conv_tab(Cin, H, W, kh, kw, ph, pw, device):
+    """Tap table of the implicit-GEMM convolution (hecka_conv_x3_f32): for tap k = (c, i, j) the element offset of
+    x[c][h + i - ph][w + j - pw] from x[0][h][w], and (di << 16) | (dj & 0xffff)."""
+    key = (Cin, H, W, kh, kw, ph, pw, str(device))
+    if key not in _TABS:
+        k = torch.arange(Cin * kh * kw, dtype=torch.int64)
+        c, i, j = k // (kh * kw), (k // kw) % kh, k % kw
+        di, dj = i - ph, j - pw
+        tab = torch.stack([(c * H + di) * W + dj, (di << 16) | (dj & 0xffff)], dim=1)
+        if len(_TABS) > 256:
+            _TABS.clear()
+        _TABS[key] = tab.to(torch.int32).contiguous().to(device)
+    return _TABS[key]
+
+
+def _conv_x3_ok(geom, M, rows, K, N, Cin, H, W):
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    return (os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0' and os.environ.get('HECKA_CONV_X3', '1') != '0'
+            and sh == 1 and sw == 1 and dh == 1 and dw == 1 and 2 * ph == kh - 1 and 2 * pw == kw - 1
+            and bool(_lib.lib().hecka_conv_x3_eligible(M, rows, K, N, Cin, H, W)))
+
+
+def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride):
+    """Y [M,N,rows,H,W] = alpha * implicit-GEMM convolution of X [M|1,N,Cin,H,W] with A [M,rows,K] (see include/hecka.h)."""
+    Y = torch.empty((M, N, rows, H, W), device=X.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_conv_x3_f32(A.data_ptr(), X.data_ptr(), Y.data_ptr(), tab.data_ptr(), M, rows, K, rows * K,
+                                            sX, N, Cin, H, W, float(alpha), amaxA.data_ptr(), amaxB.data_ptr(),
+                                            int(amaxB_stride), torch.cuda.current_stream().cuda_stream), 'conv_x3')
+    return Y
+
+
 class BatchedConv2d(torch.autograd.Function):
     """y[m] = conv2d(x[m] | x, scale * W[m], bias_scale * b[m]);  x [M,N,C,H,W] or [N,C,H,W] (shared),
     W [M,O,C,kh,kw], b [M,O] | None  ->  y [M,N,O,Ho,Wo].  groups = 1, zero padding."""
@@ -63,6 +97,16 @@ class BatchedConv2d(torch.autograd.Function):
             raise RuntimeError('Conv2d kernel %s is larger than the padded input %s' % ((kh, kw), (H, Wd)))
         K, Q = C * kh * kw, N * Ho * Wo
         has_bias = b is not None
+        if not has_bias and _conv_x3_ok(geom, M, O, K, N, C, H, Wd):
+            # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
+            Wf = W.reshape(M, O, K).contiguous()
+            xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
+            wmax = _absmax_rows(Wf.reshape(M, -1), M)
+            y = _conv_x3(Wf, x5, M, O, K, 0 if shared else N * C * H * Wd, N, C, H, Wd,
+                         _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device), scale, wmax, xmax, 0 if shared else 1)
+            ctx.save_for_backward(x5, W, None, xmax, wmax)
+            ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
+            return y
         cols = _im2col(x5, geom, has_bias)
         Wf = W.reshape(M, O, K)
         if has_bias:      # bias rides as weight column K against the row of ones; alpha = scale rescales it
@@ -92,9 +136,18 @@ class BatchedConv2d(torch.autograd.Function):
         scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo) = ctx.cfg
         M, O, C, kh, kw = W.shape
         K, Q = C * kh * kw, N * Ho * Wo
-        dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
+        dy = dy.contiguous()
         dx = dW = db = None
-        dymax = _absmax_rows(dyq.view(M, -1), M) if xmax is not None else None
+        dymax = _absmax_rows(dy.view(M, -1), M) if xmax is not None else None
+        H, Wd = x5.shape[3], x5.shape[4]
+        if ctx.needs_input_grad[0] and dymax is not None and _conv_x3_ok(geom, M, C, O * kh * kw, N, O, H, Wd):
+            # input gradient as an implicit-GEMM convolution of dy with the rotated weights: no dgrad patch matrix, no col2im
+            Wrot = W.flip(3, 4).transpose(1, 2).reshape(M, C, O * kh * kw).contiguous()
+            dx = _conv_x3(Wrot, dy, M, C, O * kh * kw, N * O * H * Wd, N, O, H, Wd,
+                          _conv_tab(O, H, Wd, kh, kw, kh - 1 - geom[4], kw - 1 - geom[5], dy.device), scale, wmax, dymax, 1)
+            dx = dx.sum(0) if shared else dx
+        need_dgrad = ctx.needs_input_grad[0] and dx is None
+        dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             if cols is None:
                 cols = _im2col(x5, geom, has_bias)
@@ -108,7 +161,7 @@ class BatchedConv2d(torch.autograd.Function):
             if has_bias:
                 db = dWf[:, :, K] * (bias_scale / scale)
             del cols
-        if ctx.needs_input_grad[0]:
+        if need_dgrad:
             Wt = W.reshape(M, O, K).transpose(1, 2).contiguous()                              # [M,K,O]
             if dymax is not None and _x3_eligible(M, K, Q, O):
                 dcols = _bgemm_x3(Wt, dyq, M, K, Q, O, K * O, O * Q, True, scale, wmax, dymax, 1)

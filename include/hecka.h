@@ -214,6 +214,18 @@ int hecka_bgemm_x3_f32(const float* A, const float* B, float* C, int batch, int 
                        long long strideB, int nn, float alpha, const float* amaxA, const float* amaxB, int amaxB_stride,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Implicit-GEMM convolution on the fp16-split tile, unit stride and dilation, output as large as the input:
+ *   Y[b][n][r][h][w] = alpha * sum_k A[b][r][k] * X[b][n][c_k][h + di_k][w + dj_k]   (zero outside the image)
+ * A [batch, rows, K] (strideA between batches), X [batch | shared, N, Cin, H, W] (strideX, 0 = shared), Y [batch, N, rows,
+ * H, W]; tab [K][2] int32 per tap k: { (c_k H + di_k) W + dj_k , (di_k << 16) | (dj_k & 0xffff) }.  No patch matrix is
+ * written or read.  Forward of Conv2d: A = weights [O, C kh kw], di = i - pad.  Input gradient: A = rotated weights
+ * [C, O kh kw], X = dy, di = i - (kh - 1 - pad): replaces the dgrad GEMM and hecka_col2im_f32.  amaxA / amaxB as for
+ * hecka_bgemm_x3_f32.  rows % 64 == 0, N H W % 128 == 0, K % 16 == 0 (hecka_conv_x3_eligible). */
+int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, int W);
+int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                      long long strideA, long long strideX, int N, int Cin, int H, int W, float alpha, const float* amaxA,
+                      const float* amaxB, int amaxB_stride, void* stream);
+
 /* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
  * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
  * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an
