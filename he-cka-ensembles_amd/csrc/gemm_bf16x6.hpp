@@ -115,6 +115,14 @@ struct implicit_b : std::false_type {};
 template <class P>
 struct implicit_b<P, std::void_t<decltype(P::kImplicitB)>> : std::bool_constant<P::kImplicitB> {};
 
+// Likewise for an NT product (Pro::kImplicitNT = true): both operands come from pro - pro.seek(kt) positions it on k-tile
+// kt (calls come with kt increasing by one), pro.avoff(i) is the byte offset of this thread's A quad of row block i,
+// pro.btoff(i, c) that of element c of its B quad (element-wise, so that a quad may straddle an image border).
+template <class P, class = void>
+struct implicit_nt : std::false_type {};
+template <class P>
+struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constant<P::kImplicitNT> {};
+
 // Product tile out[i,j] = sum_k A[i,k] B(k,j), interior tiles only (rows/cols multiples of the tile, (kend - kbeg) a
 // multiple of 16, 16-byte aligned A rows).  A is [rows, K] (k contiguous).  NN = false: B is [cols, K] (k contiguous,
 // 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
@@ -180,9 +188,12 @@ struct GemmTileX6 {
     auto gload_a = [&](auto SET, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(SET)::value;
       const unsigned so = sA0 + (unsigned)kt * (unsigned)(kX6BK * SA);
+      if constexpr (implicit_nt<Pro>::value) pro.seek(kt);
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
-        if (EA == kElemF32) {
+        if constexpr (implicit_nt<Pro>::value) {
+          ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)pro.avoff(i), 0, 0));
+        } else if (EA == kElemF32) {
           ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[i], (int)so, 0));
         } else {
           const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)aoff[i], (int)so, 0);
@@ -211,6 +222,10 @@ struct GemmTileX6 {
             else
               rb[S][i][c] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsB, (int)bgoff[i], so, 0));
           }
+        } else if constexpr (implicit_nt<Pro>::value) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)pro.btoff(i, c), 0, 0));
         } else {
           const int so = (int)(sB0 + (unsigned)kt * (unsigned)(kX6BK * SB));
           if (EB == kElemF32) {

@@ -1038,6 +1038,94 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
   });
 }
 
+// Weight gradient of the same convolutions, both operands implicit:
+//   dW[b][o][r] = alpha * sum_q dy[b][n_q][o][h_q][w_q] * X[b][n_q][c_r][h_q + di_r][w_q + dj_r],   q = (n, h, w)
+// an NT product over k = q (split over K, fixed-order second stage).  A: dy as it lies in NCHW - 16 consecutive q of one
+// image are contiguous for a channel; B: the patch row r = (c, i, j), gathered element by element (a quad may straddle
+// the image border).  The thread keeps (n, h, w) of its quad and advances it by 16 positions per k-tile - no division,
+// no table in the loop.  Rows r beyond C kh kw (R is padded to a multiple of 128) have a tap that is never in range.
+struct ConvWgradPro {
+  static constexpr bool kImplicitNT = true;
+  float sa, sb;
+  int O, C, H, W, S;       // dy channels, x channels, image
+  int n, h, w, cur;        // this thread's quad: q = (n, h, w .. w+3) of k-tile `cur`
+  int dw16, dh16;          // 16 % W, 16 / W
+  int arow[2];             // A rows (output channels) of the thread's quads, times S
+  int boff[2], bdi[2], bdj[2];   // B rows (taps): element offset, di, dj
+  template <class T> __device__ __forceinline__ void prefetch(T, int) {}
+  template <class T> __device__ __forceinline__ void stageA(T, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sa;
+  }
+  template <class T> __device__ __forceinline__ void stageB(T, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sb;
+  }
+  __device__ __forceinline__ void seek(int kt) {
+    while (cur < kt) {
+      w += dw16;
+      if (w >= W) { w -= W; ++h; }
+      h += dh16;
+      while (h >= H) { h -= H; ++n; }
+      ++cur;
+    }
+  }
+  __device__ __forceinline__ unsigned avoff(int i) const { return (unsigned)(n * O * S + arow[i] + h * W + w) * 4u; }
+  __device__ __forceinline__ unsigned btoff(int i, int c) const {
+    const int hh = h + bdi[i], ww = w + c + bdj[i];
+    const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+    return ok ? (unsigned)((n * C * H + h) * W + w + c + boff[i]) * 4u : 0xFFFFFFF0u;
+  }
+};
+
+template <int TM>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                                    float* __restrict__ out, const int2* __restrict__ tab,
+                                                                    int O, int Rp, long long strideX, int N, int C, int H,
+                                                                    int W, const float* __restrict__ amaxA,
+                                                                    const float* __restrict__ amaxB, int amaxB_stride,
+                                                                    float alpha, int tilesM, int tilesN, int kchunk,
+                                                                    long long slab) {
+  using Tile = GemmTileX6<TM, 128, false, ConvWgradPro, 1, true>;
+  __shared__ typename Tile::Smem sm;
+  const int per = tilesM * tilesN;
+  const int b = blockIdx.x / per, tl = blockIdx.x % per;
+  const int ti = tl % tilesM, tj = tl / tilesM;
+  const int S = H * W, Q = N * S;
+  const int kbeg = blockIdx.y * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > Q) kend = Q;
+  ConvWgradPro pro;
+  pro.sa = pow2_scale(amaxA[b], 14);
+  pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
+  pro.O = O; pro.C = C; pro.H = H; pro.W = W; pro.S = S;
+  pro.dw16 = 16 % W;
+  pro.dh16 = 16 / W;
+  {
+    const int t = threadIdx.x, kq = t & 3, srow = t >> 2;
+    const int q = kbeg + 4 * kq;
+    pro.n = q / S;
+    const int rem = q - pro.n * S;
+    pro.h = rem / W;
+    pro.w = rem - pro.h * W;
+    pro.cur = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      pro.arow[i] = (ti * TM + srow + 64 * i) * S;     // (i = 1 is unused by the 64-row tile)
+      const int2 e = tab[tj * 128 + srow + 64 * i];
+      pro.boff[i] = e.x;
+      pro.bdi[i] = e.y >> 16;
+      pro.bdj[i] = (int)(short)(e.y & 0xffff);
+    }
+  }
+  const float unscale = (gridDim.y > 1 ? 1.0f : alpha) / (pro.sa * pro.sb);
+  Tile tile;
+  tile.run(sm, dY + (size_t)b * N * O * S, (unsigned)((size_t)N * O * S * 4u), Q, X + (size_t)b * strideX,
+           (unsigned)((size_t)N * C * S * 4u), Q, ti * TM, tj * 128, kbeg, kend, pro);
+  float* o = out + (size_t)blockIdx.y * slab + (size_t)b * O * Rp;
+  tile.for_each([&](int lr, int lc, float v) { o[(size_t)(ti * TM + lr) * Rp + tj * 128 + lc] = v * unscale; });
+}
+
 // ------------------------------------------------------------------------------------------
 // (7) row-wise helpers for the un-fused functional API (center_gram and its backward).
 //     HBM-bound elementwise passes over [rows, cols].
@@ -2465,6 +2553,61 @@ int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, 
   else { if (fold) HECKA_CX3(true, 64); else HECKA_CX3(false, 64); }
 #undef HECKA_CX3
   return check_launch("conv_x3");
+}
+
+static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
+  const long long tiles = (long long)batch * (O / (O % 128 ? 64 : 128)) * (Rp / 128);
+  long long want = (1024 + tiles - 1) / tiles, maxs = Q / 1024;
+  if (want > maxs) want = maxs;
+  return want >= 2 ? (int)want : 1;
+}
+
+int hecka_conv_wgrad_x3_eligible(int batch, int O, int Rp, int N, int C, int H, int W) {
+  const long long S = (long long)H * W, Q = (long long)N * S;
+  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && O > 0 && Rp > 0 && N > 0 && C > 0 && H > 0 && W > 0 && O % 64 == 0 &&
+         Rp % 128 == 0 && Q % 16 == 0 && W % 4 == 0 && (W >= 16 ? W % 16 == 0 : 16 % W == 0) &&
+         (long long)N * O * S < (1ll << 30) && (long long)N * C * S < (1ll << 30) && Q < (1ll << 31) &&
+         (long long)batch * O * Rp < (1ll << 31);
+}
+
+size_t hecka_conv_wgrad_x3_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W) {
+  if (!hecka_conv_wgrad_x3_eligible(batch, O, Rp, N, C, H, W)) return 0;
+  const int ns = conv_wgrad_nsplit(batch, O, Rp, (long long)N * H * W);
+  return ns > 1 ? (size_t)ns * batch * O * Rp * sizeof(float) : 0;
+}
+
+int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
+                            long long strideX, int N, int C, int H, int W, float alpha, const float* amaxA,
+                            const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  if (!dY || !X || !dW || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_wgrad_x3: null pointer%s");
+  if (!hecka_conv_wgrad_x3_eligible(batch, O, Rp, N, C, H, W) || !aligned16(dY) || (reinterpret_cast<uintptr_t>(tab) & 7))
+    return fail(HECKA_EINVAL, "conv_wgrad_x3: shape not eligible (see hecka_conv_wgrad_x3_eligible)%s");
+  const long long Q = (long long)N * H * W;
+  const int ns = conv_wgrad_nsplit(batch, O, Rp, Q);
+  const size_t need = ns > 1 ? (size_t)ns * batch * O * Rp * sizeof(float) : 0;
+  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "conv_wgrad_x3: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  const int tm = O % 128 ? 64 : 128;
+  const int tilesM = O / tm, tilesN = Rp / 128;
+  const int kchunk = (int)((((Q / 16) + ns - 1) / ns) * 16);
+  dim3 grid((unsigned)((long long)batch * tilesM * tilesN), ns);
+  hipStream_t st = (hipStream_t)stream;
+  float* out = ns > 1 ? (float*)ws : dW;
+  const long long slab = (long long)batch * O * Rp;
+  const int2* t2 = reinterpret_cast<const int2*>(tab);
+  if (tm == 128)
+    hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
+                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab);
+  else
+    hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
+                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab);
+  if (int rc = check_launch("conv_wgrad_x3")) return rc;
+  if (ns > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)slab,
+                       dW, alpha);
+    return check_launch("conv_wgrad_x3 (reduce)");
+  }
+  return HECKA_OK;
 }
 
 static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,

@@ -49,15 +49,19 @@ def _col2im(dcols, M, N, C, H, W, geom):
 _TABS = {}
 
 
-def _conv_tab(Cin, H, W, kh, kw, ph, pw, device):
+def _conv_tab(Cin, H, W, kh, kw, ph, pw, device, rows=None):
     """Tap table of the implicit-GEMM convolution (hecka_conv_x3_f32): for tap k = (c, i, j) the element offset of
-    x[c][h + i - ph][w + j - pw] from x[0][h][w], and (di << 16) | (dj & 0xffff)."""
-    key = (Cin, H, W, kh, kw, ph, pw, str(device))
+    x[c][h + i - ph][w + j - pw] from x[0][h][w], and (di << 16) | (dj & 0xffff).  `rows` pads the table with taps that
+    are never in range (the weight-gradient kernel's patch rows beyond C kh kw)."""
+    key = (Cin, H, W, kh, kw, ph, pw, str(device), rows)
     if key not in _TABS:
         k = torch.arange(Cin * kh * kw, dtype=torch.int64)
         c, i, j = k // (kh * kw), (k // kw) % kh, k % kw
         di, dj = i - ph, j - pw
         tab = torch.stack([(c * H + di) * W + dj, (di << 16) | (dj & 0xffff)], dim=1)
+        if rows is not None and rows > tab.shape[0]:
+            pad = torch.tensor([[0, (-30000 << 16)]], dtype=torch.int64).expand(rows - tab.shape[0], 2)
+            tab = torch.cat([tab, pad])
         if len(_TABS) > 256:
             _TABS.clear()
         _TABS[key] = tab.to(torch.int32).contiguous().to(device)
@@ -147,8 +151,25 @@ class BatchedConv2d(torch.autograd.Function):
                           _conv_tab(O, H, Wd, kh, kw, kh - 1 - geom[4], kw - 1 - geom[5], dy.device), scale, wmax, dymax, 1)
             dx = dx.sum(0) if shared else dx
         need_dgrad = ctx.needs_input_grad[0] and dx is None
+        Rp = (K + 127) // 128 * 128
+        L = _lib.lib()
+        if (ctx.needs_input_grad[1] and not has_bias and dymax is not None and geom[2:] == (1, 1, geom[4], geom[5], 1, 1)
+                and 2 * geom[4] == kh - 1 and 2 * geom[5] == kw - 1 and os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0'
+                and os.environ.get('HECKA_CONV_X3', '1') != '0' and L.hecka_conv_wgrad_x3_eligible(M, O, Rp, N, C, H, Wd)):
+            # weight gradient with both operands implicit: dy as it lies (NCHW), patches gathered in the kernel
+            dWp = torch.empty((M, O, Rp), device=dy.device, dtype=torch.float32)
+            nbytes = L.hecka_conv_wgrad_x3_workspace_bytes(M, O, Rp, N, C, H, Wd)
+            ws = torch.empty((max(nbytes, 4) // 4,), device=dy.device, dtype=torch.float32)
+            _lib.check(L.hecka_conv_wgrad_x3_f32(
+                dy.data_ptr(), x5.data_ptr(), dWp.data_ptr(),
+                _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], dy.device, rows=Rp).data_ptr(), M, O, Rp,
+                0 if shared else N * C * H * Wd, N, C, H, Wd, float(scale), dymax.data_ptr(), xmax.data_ptr(),
+                0 if shared else 1, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), 'conv_wgrad_x3')
+            dW = dWp[:, :, :K].reshape(W.shape)
+        if dW is not None and not need_dgrad:
+            return dx, dW, db, None, None, None
         dyq = dy.transpose(1, 2).reshape(M, O, Q).contiguous()
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        if dW is None and (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])):
             if cols is None:
                 cols = _im2col(x5, geom, has_bias)
             R = cols.shape[1]

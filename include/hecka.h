@@ -226,6 +226,17 @@ int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, 
                       long long strideA, long long strideX, int N, int Cin, int H, int W, float alpha, const float* amaxA,
                       const float* amaxB, int amaxB_stride, void* stream);
 
+/* Weight gradient of the same convolutions with BOTH operands implicit (no patch matrix, no [O,Q] copy of dy):
+ *   dW[b][o][r] = alpha * sum_{n,h,w} dY[b][n][o][h][w] * X[b][n][c_r][h + di_r][w + dj_r]
+ * dY [batch,N,O,H,W], X [batch | shared,N,C,H,W], dW [batch,O,Rp] with Rp = C kh kw rounded up to a multiple of 128; tab
+ * [Rp][2] as for hecka_conv_x3_f32 with rows r >= C kh kw marked never-in-range (di = -30000).  Split over K = N H W with a
+ * fixed-order second stage: ws >= hecka_conv_wgrad_x3_workspace_bytes(...).  W % 16 == 0 or 16 % W == 0, O % 64 == 0. */
+int hecka_conv_wgrad_x3_eligible(int batch, int O, int Rp, int N, int C, int H, int W);
+size_t hecka_conv_wgrad_x3_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W);
+int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
+                            long long strideX, int N, int C, int H, int W, float alpha, const float* amaxA,
+                            const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes, void* stream);
+
 /* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
  * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
  * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an
