@@ -1556,14 +1556,16 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 }
 
 // dx[m,n,c,h,w] = sum over the patches that read this pixel (a gather: deterministic, no atomics)
+template <typename IT = long long>
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, ConvGeom g, int R,
                                                      float* __restrict__ dx) {
-  const long long total = (long long)g.N * g.C * g.H * g.W;
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const IT total = (IT)g.N * (IT)g.C * (IT)g.H * (IT)g.W;
+  const IT e = (IT)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int m = blockIdx.y;
-  const int w = (int)(e % g.W), h = (int)((e / g.W) % g.H), c = (int)((e / ((long long)g.W * g.H)) % g.C);
-  const int n = (int)(e / ((long long)g.W * g.H * g.C));
+  const IT t1 = e / (IT)g.W, t2 = t1 / (IT)g.H;
+  const int w = (int)(e - t1 * (IT)g.W), h = (int)(t1 - t2 * (IT)g.H);
+  const int n = (int)(t2 / (IT)g.C), c = (int)(t2 - (IT)n * (IT)g.C);
   const long long Q = (long long)g.N * g.Ho * g.Wo;
   float acc = 0.f;
   for (int i = 0; i < g.kh; ++i) {
@@ -1580,7 +1582,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
       acc += dcols[((size_t)m * R + r) * Q + ((long long)n * g.Ho + oh) * g.Wo + ow];
     }
   }
-  dx[(size_t)m * total + e] = acc;
+  dx[(size_t)m * (size_t)total + (size_t)e] = acc;
 }
 
 
@@ -2654,9 +2656,12 @@ int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int 
   if (sh == 1 && sw == 1 && dh == 1 && dw == 1 && W % 4 == 0 && total < (1ll << 31) && aligned16(dx) && !getenv("HECKA_COL2IM_GENERAL"))
     hipLaunchKernelGGL(col2im_s1_kernel, dim3((unsigned)((total / 4 + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,
                        dcols, g, rows, dx);
+  else if (total < (1ll << 31))
+    hipLaunchKernelGGL(col2im_kernel<unsigned>, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,
+                       dcols, g, rows, dx);
   else
-    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream, dcols, g,
-                       rows, dx);
+    hipLaunchKernelGGL(col2im_kernel<long long>, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,
+                       dcols, g, rows, dx);
   return check_launch("col2im");
 }
 
