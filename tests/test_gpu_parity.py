@@ -827,3 +827,29 @@ def test_fused_batchnorm_relu_matches_unfused(with_res, monkeypatch):
         outs.append([y.detach(), x.grad, w.grad, b.grad, mean, var] + ([r.grad] if with_res else []))
     for a, b_ in zip(*outs):
         assert _relerr(a.cpu().numpy(), b_.cpu().double().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize('k,H,W,N,C,O', [((5, 5), 8, 8, 8, 64, 128), ((1, 1), 16, 4, 8, 128, 64), ((3, 5), 4, 32, 4, 64, 64),
+                                         ((3, 3), 2, 16, 8, 128, 128)])
+def test_implicit_conv_geometries_match_fp64(k, H, W, N, C, O):
+    """hecka_conv_x3_f32 / hecka_conv_wgrad_x3_f32 away from the ResNet geometry: 5x5, 1x1 and rectangular kernels,
+    non-square images whose rows are shorter (W = 4: four image rows per 16-position k-tile) and longer (W = 32) than a
+    k-tile, padded patch rows (C kh kw not a multiple of 128) - against F.conv2d per member in fp64."""
+    import torch.nn.functional as F
+    from hyper_amd.layers.conv import BatchedConv2d, _conv_x3_ok
+    dev = _dev()
+    torch.manual_seed(sum(k) + H + W)
+    M = 2
+    geom = (k[0], k[1], 1, 1, (k[0] - 1) // 2, (k[1] - 1) // 2, 1, 1)
+    assert _conv_x3_ok(geom, M, O, C * k[0] * k[1], N, C, H, W)
+    x = torch.randn(M, N, C, H, W, device=dev, requires_grad=True)
+    Wt = (torch.randn(M, O, C, k[0], k[1], device=dev) * 0.05).requires_grad_(True)
+    up = torch.randn(M, N, O, H, W, device=dev)
+    y = BatchedConv2d.apply(x, Wt, None, 1.3, 1.0, geom)
+    (y * up).sum().backward()
+    xd, Wd = x.detach().cpu().double().requires_grad_(True), Wt.detach().cpu().double().requires_grad_(True)
+    yd = torch.stack([F.conv2d(xd[m], 1.3 * Wd[m], None, 1, (geom[4], geom[5])) for m in range(M)])
+    (yd * up.cpu().double()).sum().backward()
+    assert _relerr(y.detach().cpu().numpy(), yd.detach().numpy()) <= RTOL
+    assert _relerr(x.grad.cpu().numpy(), xd.grad.numpy()) <= RTOL
+    assert _relerr(Wt.grad.cpu().numpy(), Wd.grad.numpy()) <= RTOL
