@@ -245,6 +245,33 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
 // Split-precision variants of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands
 // split on the way into LDS (gemm_bf16x6.hpp).  SCHEME 0: three bf16 terms.  SCHEME 1: two fp16 terms of the centred
 // value scaled by s = 2^k, k from xmax[m] so that |x - sbar| * s <= 2 xmax s <= 2^14; the epilogue undoes s^2.
+// tile index within a member -> (I <= J).  HECKA_TILE_ORDER 1: the off-diagonal tiles first, the diagonal ones last
+#ifndef HECKA_TILE_ORDER
+#define HECKA_TILE_ORDER 0
+#endif
+__device__ __forceinline__ void tri_tile(int rem, int ntile, int& I, int& J) {
+  if (HECKA_TILE_ORDER) {
+    const int noff = ntile * (ntile - 1) / 2;
+    if (rem >= noff) {
+      I = J = rem - noff;
+      return;
+    }
+    I = 0;
+    while (rem >= ntile - 1 - I) {
+      rem -= ntile - 1 - I;
+      ++I;
+    }
+    J = I + 1 + rem;
+    return;
+  }
+  I = 0;
+  while (rem >= ntile - I) {
+    rem -= ntile - I;
+    ++I;
+  }
+  J = I + rem;
+}
+
 #ifndef HECKA_DIAG_TILES
 #define HECKA_DIAG_TILES 1
 #endif
@@ -317,12 +344,8 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   __shared__ float cA[128], cB[128], ssum;
   int m, rem;
   member_tile_w(w, ntile * (ntile + 1) / 2, xcd_map, m, rem);
-  int I = 0;
-  while (rem >= ntile - I) {
-    rem -= ntile - I;
-    ++I;
-  }
-  const int J = I + rem;
+  int I, J;
+  tri_tile(rem, ntile, I, J);
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * 2u;
   RawProX6<1> pro;
   pro.sbar = sbar + (size_t)m * P;
@@ -381,12 +404,8 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   __shared__ float cA[128], cB[128];
   int m, rem;
   member_tile_w(w, ntile * (ntile + 1) / 2, xcd_map, m, rem);
-  int I = 0;
-  while (rem >= ntile - I) {
-    rem -= ntile - I;
-    ++I;
-  }
-  const int J = I + rem;
+  int I, J;
+  tri_tile(rem, ntile, I, J);
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * ES;
   CenterProX6<SCHEME> pro;
   pro.sbar = sbar + (size_t)m * P;
