@@ -1,5 +1,5 @@
 """Gradient error of the full HE layer at bench member / sample counts vs the fp64 oracle (same GPU): how much of the
-1e-5 budget each GEMM variant uses.   python tools/grad_margin.py"""
+1e-5 budget each GEMM variant uses.   python tests/grad_margin.py (a checker: uses oracle/, so it lives under tests/; not collected by pytest)"""
 import os
 import sys
 from collections import OrderedDict
