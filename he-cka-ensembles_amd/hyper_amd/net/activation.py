@@ -33,6 +33,8 @@ def activation_gamma(act):
         return 1.0
     if isinstance(act, (int, float)):
         return float(act)
+    if isinstance(act, type):       # a torch.nn activation class names its function
+        act = {'ReLU': 'relu', 'LeakyReLU': 'leaky_relu', 'GELU': 'gelu', 'Crater': 'crater'}.get(act.__name__, act)
     if isinstance(act, str):
         return {'crater': 1.0000000001, 'gelu': 1.70092624336, 'leaky_relu': 1.70483162718,
                 'relu': math.sqrt(2.0 / (1.0 - (1.0 / math.pi)))}.get(act, 1.0)

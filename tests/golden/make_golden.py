@@ -295,6 +295,79 @@ def run_svgd_step(dtype, tag):
     print('svgd_step', tag, 'loss', float(loss))
 
 
+HYPER_HE = he('cossim', eps=0.0025, arc_eps=0.065)
+HYPER_W = {'name': 'start_end_linear', 'first_layer': 0.03, 'middle_start': 0.60, 'middle_increase': 1.80, 'last_layer': 6.8}
+HYPER = {
+    'hyper': {'name': 'mlp_layer_code_generator', 'latent_size': 38, 'dim_multiplier': 2.84, 'mlp_dims': 4, 'bias': True,
+              'sn_coeff': 6.0,
+              'layer_code_generator': {
+                  'name': 'layer_generator', 'code_size': 26,
+                  'default_generators': {
+                      'conv2d': {'name': 'mlp_sampled_conv_generator', 'input_size': 26, 'dim_multiplier': 2.755,
+                                 'mlp_dims': 1, 'bias': True, 'sn_coeff': 3.0},
+                      'linear': {'name': 'mlp_layer_generator', 'input_size': 26, 'dim_multiplier': 3.065, 'mlp_dims': 4,
+                                 'norm_last': True, 'affine_last': True, 'bias': True, 'sn_coeff': 3.0},
+                      'final_linear': {'name': 'mlp_layer_generator', 'input_size': 26, 'dim_multiplier': 3.011,
+                                       'mlp_dims': 2, 'norm_last': False, 'norm_before_last': False, 'affine_last': True,
+                                       'bias': True, 'sn_coeff': 3.0}},
+                  'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}}},
+    'method': {'name': 'repulsive_kernel', 'num': 4, 'gamma': 10.151, 'gamma_ood': 3.688, 'beta_ood': 0.0673,
+               'l2_reg': 0.0717, 'warmup': 2075,
+               'model_kernel': layers(HYPER_HE, HYPER_W), 'model_kernel_ood': layers(HYPER_HE, HYPER_W),
+               'ind_loss': {'name': 'cross_entropy'}, 'ood_loss': {'name': 'mean_softmax_entropy'}},
+}
+
+
+def run_hyper_step(dtype, tag):
+    """One training step of configs/mnist/hyper/mlp-he.yml (the `hyper:` and `method:` sections as shipped, 4 members)
+    with the REAL reference: latent -> code mixer MLP -> layer generators (spectral-norm Linear + GroupNorm + GELU)
+    -> LeNet-5 parameters -> batched forward on 10 inlier + 4 outlier images -> RepulsiveKernel loss (cossim HE on
+    inliers and outliers, OOD entropy, L2 on the generated weights) -> backward.  Records the generated parameters,
+    a digest of every hypernetwork gradient and the power-iteration buffers after the step; the hypernetwork's state is
+    the deterministic fill of tests/golden/fill.py (70 M weights are not committed)."""
+    import hyper.target.lenet  # noqa: F401
+    from hyper.generators.base import build_generator
+    import hyper.generators.mlp  # noqa: F401
+    import hyper.layers.generators  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    from hyper.util.collections import flatten_keys
+    rk.KERN_PARAMS['cossim'] = {'eps': 1e-6}
+    torch.manual_seed(63)
+    hyper = build_generator(HYPER['hyper']).to(dtype)
+    method = build_method(HYPER['method']).to(dtype)
+    hyper.train()
+    gen = torch.Generator().manual_seed(10)
+    Z = torch.randn(4, 38, generator=gen, dtype=torch.float64).to(dtype)
+    X = torch.randn(14, 1, 28, 28, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 10, (10,), generator=gen)
+    sys.path.insert(0, OUT)
+    from fill import fill_state, grad_digest, state_stats
+    stats = state_stats(hyper)
+    fill_state(hyper, stats)
+    rec = {'config': json.dumps(HYPER), 'Z': Z.numpy(), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 1500, 'ood_N': 4,
+           'stats': json.dumps(stats), 'state_keys': json.dumps(list(hyper.state_dict().keys()))}
+    trainer = types.SimpleNamespace(training=True)
+    params = hyper.forward_params(Z)
+    track = hyper(params=params, x=X, sample_params=False, ret_params=True, feature_split=True, ood_N=4)
+    track = method(trainer, track['params'], [], track, X[:10], Y, step=1500)
+    track['loss'].backward()
+    for k, v in flatten_keys(params).items():
+        rec['p:' + k] = v.detach().numpy()
+    rec.update({'loss': track['loss'].detach().numpy(), 'ind_loss': track['ind_loss'].detach().numpy(),
+                'ood_loss': track['ood_loss'].detach().numpy(), 'ind_rep_loss': track['ind_rep_loss'].detach().numpy(),
+                'ood_rep_loss': track['ood_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy(),
+                'feat_keys': json.dumps(list(track['feats_ind'].keys()))})
+    for k, v in hyper.state_dict().items():
+        if k.endswith(('weight_u', 'weight_v', 'weight_sigma')):
+            rec['after:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = grad_digest(k, v.grad)
+    np.savez_compressed(os.path.join(OUT, 'hyper_train_step_%s.npz' % tag), **rec)
+    print('hyper_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']),
+          float(track['ood_rep_loss']), 'keys', len(hyper.state_dict()))
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -326,11 +399,15 @@ def run_conv_case(name, kwargs, M, xshape, dtype):
 
 def main():
     mk = _import_reference()
+    if '--hyper-only' in sys.argv:
+        run_hyper_step(torch.float64, 'f64')
+        return
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         run_train_step(dtype, tag)
         run_lenet_step(dtype, tag)
     run_resnet_step(torch.float64, 'f64')
     run_svgd_step(torch.float64, 'f64')
+    run_hyper_step(torch.float64, 'f64')
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)

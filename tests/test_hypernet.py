@@ -1,0 +1,123 @@
+"""Hypernetwork sampler side: `mlp_layer_code_generator` -> `layer_generator` -> layer generators,
+against one training step of configs/mnist/hyper/mlp-he.yml run by the REAL reference
+(tests/golden/hyper_train_step_f64.npz, made by tests/golden/make_golden.py::run_hyper_step).
+
+CPU part (here): the generators are shared-weight torch modules, so parameter generation is checked in fp64 without a
+GPU - state-dict keys, generated LeNet parameters, power-iteration buffers after the forward, RNG-order of the
+initialisation.  GPU part (marked gpu): the whole step - generated parameters through the batched LeNet on libhecka,
+RepulsiveKernel with inlier + outlier HE terms, backward into the hypernetwork."""
+import json
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, 'golden')]
+from fill import fill_state, grad_digest  # noqa: E402
+
+GOLD = os.path.join(HERE, 'golden', 'hyper_train_step_f64.npz')
+
+
+def _build(dtype):
+    import hyper_amd.target.lenet  # noqa: F401
+    from hyper_amd.generators import build_generator
+    gold = np.load(GOLD)
+    cfg = json.loads(str(gold['config']))
+    torch.manual_seed(63)
+    hyper = build_generator(cfg['hyper']).to(dtype)
+    return gold, cfg, hyper
+
+
+def test_generated_parameters_match_reference():
+    from hyper_amd.util.collections import flatten_keys
+    gold, cfg, hyper = _build(torch.float64)
+    assert list(hyper.state_dict().keys()) == json.loads(str(gold['state_keys']))
+    fill_state(hyper, json.loads(str(gold['stats'])))
+    hyper.train()
+    params = flatten_keys(hyper.forward_params(torch.from_numpy(gold['Z'])))
+    want = [k[2:] for k in gold.files if k.startswith('p:')]
+    assert list(params.keys()) == want
+    for k in want:
+        np.testing.assert_allclose(params[k].detach().numpy(), gold['p:' + k], rtol=1e-9, atol=1e-11)
+    for k, v in hyper.state_dict().items():     # one power-iteration step happened, in place
+        if k.endswith(('weight_u', 'weight_v', 'weight_sigma')):
+            np.testing.assert_allclose(v.numpy(), gold['after:' + k], rtol=1e-9, atol=1e-12)
+    # eval mode: no power iteration, same u / v -> same weights again
+    hyper.eval()
+    again = flatten_keys(hyper.forward_params(torch.from_numpy(gold['Z'])))
+    before = {k: v.clone() for k, v in hyper.state_dict().items() if k.endswith('weight_u')}
+    hyper.forward_params(torch.from_numpy(gold['Z']))
+    for k, v in hyper.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k])
+    assert all(torch.isfinite(v).all() for v in again.values())
+
+
+def test_initialisation_statistics_match_reference():
+    """Same construction order and draws as the reference: with the seed the fixture was made with, every state-dict
+    entry's initial mean / std equals the reference's (the fixture keeps those scalars)."""
+    gold, cfg, hyper = _build(torch.float64)
+    stats = json.loads(str(gold['stats']))
+    for k, v in hyper.state_dict().items():
+        mean, std = stats[k]
+        assert abs(float(v.mean()) - mean) <= 1e-6 + 1e-5 * abs(mean), k
+        assert abs((float(v.std(unbiased=False)) if v.numel() > 1 else 0.0) - std) <= 1e-6 + 1e-5 * abs(std), k
+
+
+def test_code_layout_and_errors():
+    gold, cfg, hyper = _build(torch.float32)
+    lg = hyper.layer_gen
+    assert lg.get_total_layers() == 5 and lg.get_total_codes() == 6 + 16 + 1 + 1 + 1 and lg.code_size == 26
+    shapes = lg.get_parameter_shapes()
+    assert tuple(shapes['0']['self']['weight']) == (6, 1, 5, 5) and tuple(shapes['5']['self']['bias']) == (10,)
+    with pytest.raises(AssertionError):
+        lg.forward_params(torch.zeros(2, 3, 26))
+    with pytest.raises(ValueError):
+        hyper.forward_layer_params(torch.zeros(2, lg.get_total_codes(), 7))
+    z = hyper.sample_params(3)
+    assert z.shape == (3, 38)
+    rnd = hyper.forward_params('3', device='cpu')
+    assert rnd['3']['self'].shape == (3, 256 * 120 + 120)
+    assert hyper.sample_random_params(7) == '7'
+
+
+@pytest.mark.gpu
+def test_hypernetwork_train_step_matches_reference():
+    from hyper_amd.diversity.methods import build_method
+    import types
+    dev = torch.device('cuda:0')
+    gold, cfg, hyper = _build(torch.float32)
+    fill_state(hyper, json.loads(str(gold['stats'])))
+    hyper = hyper.to(dev).train()
+    method = build_method(cfg['method']).to(dev)
+    Z = torch.from_numpy(gold['Z']).float().to(dev)
+    X = torch.from_numpy(gold['X']).float().to(dev)
+    Y = torch.from_numpy(gold['Y']).to(dev)
+    ood = int(gold['ood_N'])
+    params = hyper.forward_params(Z)
+    track = hyper(params=params, x=X, sample_params=False, ret_params=True, feature_split=True, ood_N=ood)
+    assert list(track['feats_ind'].keys()) == json.loads(str(gold['feat_keys']))
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X[:-ood], Y, step=int(gold['step']))
+    track['loss'].backward()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+    assert rel(track['pred'].detach().cpu().numpy(), gold['pred']) <= 2e-5
+    for key in ('loss', 'ind_loss', 'ood_loss', 'ind_rep_loss', 'ood_rep_loss'):
+        assert rel(track[key].item(), gold[key]) <= 2e-5, key
+    worst = 0.0
+    for k, v in hyper.named_parameters():
+        got, want = grad_digest(k, v.grad), gold['g:' + k]
+        # norm and sum against the norm; the 64 samples against the largest of them / the rms
+        scale = max(want[0], 1e-300)
+        err = max(abs(got[0] - want[0]) / scale, abs(got[1] - want[1]) / (scale * np.sqrt(v.numel())),
+                  np.abs(got[2:] - want[2:]).max() / max(np.abs(want[2:]).max(), scale / np.sqrt(v.numel())))
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, err)
+    print('hypernetwork step: worst gradient digest error %.2e' % worst)

@@ -15,7 +15,7 @@ M, B = 64, 512
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 tot = 0.0
-for P in (4096, 2048, 1024, 512, 256):
+for P in (8192, 4096, 2048, 1024, 512):
     X = torch.randn(M, B, P, device=dev)
     sbar = torch.empty(M, P, device=dev)
     xmax = torch.empty(M, device=dev)
