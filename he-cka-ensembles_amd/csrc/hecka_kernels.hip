@@ -1872,6 +1872,92 @@ static int pairwise_nsplit(int Ma, int Mb, long long K) {
   return (int)want;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// crater activation  y = c x (1 + tanh((x + 1) / sqrt 2))  (hyper/net/activation.py:8-12), alone and fused with the 2x2
+// max pool that follows it in the LeNet convolutions (hyper/layers/conv.py:341-346).  HBM-bound, 16 bytes per lane.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float crater_f(float x) {
+  constexpr float h = 0.70710678118654752f, c = 0.70710678118654752f + 0.008274364699f;
+  return c * x * (1.0f + tanhf(h * (x + 1.0f)));
+}
+__device__ __forceinline__ float crater_df(float x) {
+  constexpr float h = 0.70710678118654752f, c = 0.70710678118654752f + 0.008274364699f;
+  const float t = tanhf(h * (x + 1.0f));
+  return c * (1.0f + t) + c * x * h * (1.0f - t * t);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void crater_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     float* __restrict__ out, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    f32x4 r;
+    if (BWD) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = g[e] * crater_df(v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = crater_f(v[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + i) = r;
+  } else {
+    for (long long j = i; j < n; ++j) out[j] = BWD ? dy[j] * crater_df(x[j]) : crater_f(x[j]);
+  }
+}
+
+// one thread: two neighbouring pooled outputs = a 2 x 4 patch of x (two 16-byte loads).  Ties keep the first element in
+// window order (0,0) (0,1) (1,0) (1,1), as torch's max_pool2d does.
+template <bool BWD>
+__global__ __launch_bounds__(256) void crater_maxpool2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ out, long long npairs, int H, int W) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= npairs) return;
+  const int W4 = W >> 2, H2 = H >> 1;
+  const long long row = t / W4;              // (image-channel, pooled row)
+  const int q = (int)(t - row * W4);
+  const long long r = row / H2;
+  const int ph = (int)(row - r * H2);
+  const float* xp = x + (r * H + 2 * ph) * (long long)W + 4 * q;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(xp), b = *reinterpret_cast<const f32x4*>(xp + W);
+  float res[2];
+  int arg[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const float v0 = crater_f(a[2 * o]), v1 = crater_f(a[2 * o + 1]), v2 = crater_f(b[2 * o]), v3 = crater_f(b[2 * o + 1]);
+    float m = v0;
+    int k = 0;
+    if (v1 > m || v1 != v1) { m = v1; k = 1; }
+    if (v2 > m || v2 != v2) { m = v2; k = 2; }
+    if (v3 > m || v3 != v3) { m = v3; k = 3; }
+    res[o] = m;
+    arg[o] = k;
+  }
+  if (!BWD) {
+    float2 y2 = make_float2(res[0], res[1]);
+    *reinterpret_cast<float2*>(out + row * (W >> 1) + 2 * q) = y2;
+  } else {
+    const float2 g = *reinterpret_cast<const float2*>(dy + row * (W >> 1) + 2 * q);
+    f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const float go = o == 0 ? g.x : g.y;
+      const int k = arg[o];
+      const float xv = k == 0 ? a[2 * o] : k == 1 ? a[2 * o + 1] : k == 2 ? b[2 * o] : b[2 * o + 1];
+      const float d = go * crater_df(xv);
+      if (k == 0) da[2 * o] = d;
+      if (k == 1) da[2 * o + 1] = d;
+      if (k == 2) db[2 * o] = d;
+      if (k == 3) db[2 * o + 1] = d;
+    }
+    float* op = out + (r * H + 2 * ph) * (long long)W + 4 * q;
+    *reinterpret_cast<f32x4*>(op) = da;
+    *reinterpret_cast<f32x4*>(op + W) = db;
+  }
+}
+
 }  // namespace hecka
 
 using namespace hecka;
@@ -2741,6 +2827,37 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
   hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
                      weight, N, C, S, training, dx, dweight, dbias, y, dres);
   return check_launch("batchnorm_act_bwd");
+}
+
+int hecka_crater_f32(const float* x, const float* dy, float* out, long long n, void* stream) {
+  clear_error();
+  if (!x || !out) return fail(HECKA_EINVAL, "crater: null pointer%s");
+  if (n <= 0 || n > (1LL << 40)) return fail(HECKA_EINVAL, "crater: size out of range%s");
+  if (!aligned16(x) || !aligned16(out) || (dy && !aligned16(dy))) return fail(HECKA_EINVAL, "crater: needs 16-byte alignment%s");
+  const long long blocks = (n + 1023) / 1024;
+  if (blocks > 0x7fffffffLL) return fail(HECKA_EINVAL, "crater: size out of range%s");
+  if (dy)
+    hipLaunchKernelGGL(crater_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, out, n);
+  else
+    hipLaunchKernelGGL(crater_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, out, n);
+  return check_launch("crater");
+}
+
+int hecka_crater_maxpool2_f32(const float* x, const float* dy, float* out, long long R, int H, int W, void* stream) {
+  clear_error();
+  if (!x || !out) return fail(HECKA_EINVAL, "crater_maxpool2: null pointer%s");
+  if (R <= 0 || H <= 0 || W <= 0) return fail(HECKA_EINVAL, "crater_maxpool2: non-positive size%s");
+  if (H % 2 != 0 || W % 4 != 0) return fail(HECKA_EINVAL, "crater_maxpool2: needs H %% 2 == 0 and W %% 4 == 0%s");
+  if (!aligned16(x) || !aligned16(out) || (dy && (reinterpret_cast<uintptr_t>(dy) & 7)))
+    return fail(HECKA_EINVAL, "crater_maxpool2: needs 16-byte alignment%s");
+  const long long npairs = R * (H / 2) * (W / 4);
+  const long long blocks = (npairs + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(HECKA_EINVAL, "crater_maxpool2: size out of range%s");
+  if (dy)
+    hipLaunchKernelGGL(crater_maxpool2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, out, npairs, H, W);
+  else
+    hipLaunchKernelGGL(crater_maxpool2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, out, npairs, H, W);
+  return check_launch("crater_maxpool2");
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,

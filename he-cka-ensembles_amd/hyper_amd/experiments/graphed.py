@@ -7,7 +7,8 @@ through torch's caching allocator, so the step can be captured once (torch.cuda.
 replayed with one launch.  No counterpart in the reference.
 
 Conditions (checked or documented):
-  * fixed member ids and fixed batch shape (the inputs are copied into static buffers before every replay);
+  * fixed member ids (or a fixed NUMBER of sampled members: hypernetwork) and fixed batch shape (the inputs are copied
+    into static buffers before every replay);
   * the method's warm-up factor is a host float baked into the capture: capture at a step >= `warmup`, or re-capture;
   * the optimizer must be capturable (torch.optim.AdamW(..., capturable=True); SGD is as it is);
   * nothing on the path may synchronise with the host (RepulsiveKernel masks a NaN repulsion with nan_to_num)."""
@@ -23,7 +24,10 @@ class GraphedTrainStep:
             raise RuntimeError('GraphedTrainStep needs GPU tensors')
         self.hyper, self.method, self.optimizer = hyper, method, optimizer
         self.x, self.y = x.clone(), y.clone()
-        self.ids = list(member_ids) if member_ids is not None else list(range(method.num))
+        # a list = those members every step; an int = that many members SAMPLED every step (hypernetwork latents are
+        # drawn inside the capture: torch's generator is capture-aware, every replay draws fresh ones)
+        self.ids = member_ids if isinstance(member_ids, int) else (
+            list(member_ids) if member_ids is not None else list(range(method.num)))
         self.step_index = step
         self.kwargs = dict(sample_params=True, ret_params=True, feature_split=True, ood_N=0)
         self.kwargs.update(forward_kwargs or {})

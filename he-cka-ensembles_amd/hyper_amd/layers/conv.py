@@ -307,6 +307,9 @@ class Conv2d(_ConvNd):
             x = x.reshape(lead + x.shape[-3:])
         y = BatchedConv2d.apply(x, W, viewed['bias'] if self.bias else None, self.scale, self.bias_scale,
                                 self._geometry())
+        if (self.act is activation.crater and self.pooling is F.max_pool2d
+                and activation.crater_maxpool2_eligible(y, self.pooling_kwargs)):
+            return activation.crater_maxpool2(y).contiguous()      # act -> 2x2 max pool in one pass
         if self.act is not None:
             y = self.act(y)
         if self.pooling is not None:

@@ -271,6 +271,16 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
                                 const float* save_rstd, const float* weight, int G, int N, int C, long long S,
                                 int training, float* dx, float* dres, float* dweight, float* dbias, void* stream);
 
+/* crater activation y = c x (1 + tanh((x + 1) / sqrt 2)) of the target nets (hyper/net/activation.py:8-12; the reference
+ * composes it from five elementwise torch ops, each a pass over the tensor).  dy == NULL: out = crater(x); otherwise
+ * out = dy * crater'(x).  n elements, 16-byte aligned. */
+int hecka_crater_f32(const float* x, const float* dy, float* out, long long n, void* stream);
+/* crater followed by the 2x2 / stride-2 max pool of a batched Conv2d (hyper/layers/conv.py:341-346: act -> pooling) in
+ * one pass: x [R, H, W] (R = members * samples * channels).  dy == NULL: out [R, H/2, W/2] = maxpool2(crater(x));
+ * otherwise out [R, H, W] = gradient w.r.t. x given dy [R, H/2, W/2] (the activated tensor is never written; ties keep
+ * the first element of the window in row-major order, as torch.max_pool2d).  H % 2 == 0, W % 4 == 0. */
+int hecka_crater_maxpool2_f32(const float* x, const float* dy, float* out, long long R, int H, int W, void* stream);
+
 /* ---- 16-bit features (BASELINE config 3: bf16 networks) ------------------------------------------------------------
  * The reference runs the same Python path on bf16 feature tensors (torch.bmm in bf16, hyper/diversity/kernels.py:122);
  * here the three kernels that touch X read bf16 / fp16 features as they lie in HBM (half the bytes, no up-cast pass),

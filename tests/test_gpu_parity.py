@@ -853,3 +853,42 @@ def test_implicit_conv_geometries_match_fp64(k, H, W, N, C, O):
     assert _relerr(y.detach().cpu().numpy(), yd.detach().numpy()) <= RTOL
     assert _relerr(x.grad.cpu().numpy(), xd.grad.numpy()) <= RTOL
     assert _relerr(Wt.grad.cpu().numpy(), Wd.grad.numpy()) <= RTOL
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 6, 24, 24), (2, 4, 16, 8, 8), (7, 2, 12), (1031,)])
+def test_crater_kernels_match_torch_expression(shape):
+    """hecka_crater_f32 / hecka_crater_maxpool2_f32 against the reference's five-op expression (activation.py:8-12)
+    and torch.max_pool2d, forward and gradient, fp32 (tolerance: a few ulp of tanhf)."""
+    import math
+    import torch.nn.functional as F
+    from hyper_amd.net import activation
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    h = math.sqrt(2.0) / 2.0
+    c = h + 0.008274364699
+
+    def expr(t):
+        return c * t * (1.0 + torch.tanh(h * (t + 1.0)))
+    x = (2.5 * torch.randn(*shape, device=dev)).requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    y = activation.crater(x)
+    up = torch.randn_like(y)
+    (y * up).sum().backward()
+    y64 = expr(x64)
+    (y64 * up.double()).sum().backward()
+    assert (y.double() - y64).abs().max().item() <= 2e-6 * y64.abs().max().item()
+    assert (x.grad.double() - x64.grad).abs().max().item() <= 2e-6 * x64.grad.abs().max().item()
+    if len(shape) >= 3 and activation.crater_maxpool2_eligible(x, {'kernel_size': 2}):
+        x2 = x.detach().clone().requires_grad_(True)
+        p = activation.crater_maxpool2(x2)
+        lead = x.shape[:-3]
+        ref_in = x.detach().clone().requires_grad_(True)
+        q = F.max_pool2d(expr(ref_in).reshape((-1,) + x.shape[-3:]), kernel_size=2)
+        q = q.view(lead + q.shape[1:])
+        assert p.shape == q.shape
+        up2 = torch.randn_like(p)
+        (p * up2).sum().backward()
+        (q * up2).sum().backward()
+        assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item()
+        assert (x2.grad - ref_in.grad).abs().max().item() <= 4e-6 * ref_in.grad.abs().max().item()
+        assert ((x2.grad != 0) == (ref_in.grad != 0)).all()      # the same element of every window took the gradient

@@ -1,13 +1,14 @@
 """Train steps/s of the reference's model configurations (BASELINE.json configs[0..2]) on synthetic data of the dataset's
 shape: FixedEnsembleModel forward -> RepulsiveKernel (cross-entropy + HE-CKA feature repulsion) -> backward -> optimizer.
 
-    python tools/train_bench.py mnist|toy|cifar [--impl amd|ref] [--steps K] [--members M] [--batch B]
+    python tools/train_bench.py mnist|toy|cifar|hyper [--impl amd|ref] [--steps K] [--members M] [--batch B]
 
 --impl amd : hyper_amd on cuda:0 (HIP kernels).
 --impl ref : the real reference on this machine's CPU cores (build container only: needs /root/reference; shims as in
              tests/golden/make_golden.py).  A reported baseline, never part of the product path.
 """
 import argparse
+import copy
 import os
 import sys
 import time
@@ -27,7 +28,24 @@ def fk(kernel, **params):
 
 def configs(members):
     mnist_w = {'name': 'start_end_linear', 'first_layer': 0.387, 'middle_start': 0.746, 'middle_increase': 1.267, 'last_layer': 3.63}
+    hyper_he = {'name': 'model_layers',
+                'layer_weighting': {'name': 'start_end_linear', 'first_layer': 0.03, 'middle_start': 0.60, 'middle_increase': 1.80, 'last_layer': 6.8},
+                'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.065, 'feature_kernel': fk('cossim')}}
     return {
+        # configs/mnist/hyper/mlp-he.yml as shipped (BASELINE configs[4]: hypernetwork, members SAMPLED every step; 300 inlier +
+        # 100 outlier images per batch)
+        'hyper': dict(members=members or 128, batch=300, ood=100, x=(1, 28, 28), classes=10, opt='adamw', sampled=True,
+                      hyper={'name': 'mlp_layer_code_generator', 'latent_size': 38, 'dim_multiplier': 2.84, 'mlp_dims': 4, 'bias': True, 'sn_coeff': 6.0,
+                             'layer_code_generator': {'name': 'layer_generator', 'code_size': 26, 'default_generators': {
+                                 'conv2d': {'name': 'mlp_sampled_conv_generator', 'input_size': 26, 'dim_multiplier': 2.755, 'mlp_dims': 1, 'bias': True, 'sn_coeff': 3.0},
+                                 'linear': {'name': 'mlp_layer_generator', 'input_size': 26, 'dim_multiplier': 3.065, 'mlp_dims': 4, 'norm_last': True,
+                                            'affine_last': True, 'bias': True, 'sn_coeff': 3.0},
+                                 'final_linear': {'name': 'mlp_layer_generator', 'input_size': 26, 'dim_multiplier': 3.011, 'mlp_dims': 2, 'norm_last': False,
+                                                  'norm_before_last': False, 'affine_last': True, 'bias': True, 'sn_coeff': 3.0}},
+                                 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}}},
+                      method={'name': 'repulsive_kernel', 'gamma': 10.151, 'gamma_ood': 3.688, 'beta_ood': 0.0673, 'l2_reg': 0.0717, 'warmup': 2075,
+                              'model_kernel': hyper_he, 'model_kernel_ood': copy.deepcopy(hyper_he),
+                              'ind_loss': {'name': 'cross_entropy'}, 'ood_loss': {'name': 'mean_softmax_entropy'}}),
         # configs/mnist/base.yml + ens/he-lin.yml
         'mnist': dict(members=members or 5, batch=300, x=(1, 28, 28), classes=10, opt='adamw',
                       hyper={'name': 'ensemble', 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
@@ -54,7 +72,7 @@ def configs(members):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('config', choices=['mnist', 'toy', 'cifar'])
+    ap.add_argument('config', choices=['mnist', 'toy', 'cifar', 'hyper'])
     ap.add_argument('--impl', default='amd', choices=['amd', 'ref'])
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
@@ -64,14 +82,17 @@ def main():
     args = ap.parse_args()
     c = configs(args.members)[args.config]
     M, B = c['members'], args.batch or c['batch']
-    c['hyper']['ensemble_size'] = M
+    if not c.get('sampled'):
+        c['hyper']['ensemble_size'] = M
+    ood = c.get('ood', 0)
+    ids = M if c.get('sampled') else list(range(M))
     c['method']['num'] = M
     if args.impl == 'ref':
         sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
         import make_golden
         make_golden._import_reference()
         import hyper.target.lenet, hyper.target.mlp, hyper.target.resnet  # noqa: F401,E401
-        import hyper.generators.ensemble  # noqa: F401
+        import hyper.generators.ensemble, hyper.generators.mlp, hyper.layers.generators  # noqa: F401,E401
         from hyper.generators.base import build_generator
         from hyper.diversity.methods import build_method
         dev = torch.device('cpu')
@@ -86,21 +107,21 @@ def main():
     params = list(hyper.parameters()) + list(method.parameters())
     opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph) if c['opt'] == 'adamw'
            else torch.optim.SGD(params, lr=0.01, momentum=0.9))
-    X = torch.randn(B, *c['x'], device=dev)
+    X = torch.randn(B + ood, *c['x'], device=dev)
     Y = torch.randint(0, c['classes'], (B,), device=dev)
     trainer = types.SimpleNamespace(training=True)
 
     def step(i):
         opt.zero_grad(set_to_none=True)
-        track = hyper(params=list(range(M)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
-        track = method(trainer, track['params'], [], track, X, Y, step=1000 + i)
+        track = hyper(params=ids, x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=ood)
+        track = method(trainer, track['params'], [], track, X, Y, step=3000 + i)
         track['loss'].backward()
         opt.step()
         return track['loss']
 
     if args.graph:
         from hyper_amd.experiments.graphed import GraphedTrainStep
-        graphed = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=list(range(M)), step=1000)
+        graphed = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=ids, step=3000, forward_kwargs={'ood_N': ood})
         step = lambda i: graphed()   # noqa: E731
     sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
     for i in range(args.warmup):
