@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--no-fused', action='store_true', help='torch default (foreach) AdamW instead of the fused kernel')
     ap.add_argument('--graph', action='store_true', help='capture the step in one HIP graph (hyper_amd.experiments.graphed)')
     args = ap.parse_args()
     c = configs(args.members)[args.config]
@@ -105,7 +106,10 @@ def main():
     hyper = build_generator(c['hyper']).to(dev)
     method = build_method(c['method']).to(dev)
     params = list(hyper.parameters()) + list(method.parameters())
-    opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph) if c['opt'] == 'adamw'
+    # fused=True: one multi-tensor kernel per step instead of ~ten foreach passes over every parameter (70 M of them in
+    # the hypernetwork); the reference's trainer takes torch's default (foreach)
+    opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph, fused=(args.impl == 'amd' and not args.no_fused))
+           if c['opt'] == 'adamw'
            else torch.optim.SGD(params, lr=0.01, momentum=0.9))
     X = torch.randn(B + ood, *c['x'], device=dev)
     Y = torch.randint(0, c['classes'], (B,), device=dev)
