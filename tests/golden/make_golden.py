@@ -318,14 +318,50 @@ HYPER = {
 }
 
 
+TOY_RBF = he('rbf', he_s=3, eps=0.0001, arc_eps=0.035, params={'param': 6.0})
+TOY_RBF_OOD = dict(name='he', he_s=3, eps=0.0001, arc_eps=0.035, feature_kernel={'name': 'feature', 'kernel': 'rbf', 'params': {'param': 6.0}})
+TOY_W = {'name': 'list', 'weights': [0.05, 0.35, 0.85, 1.0]}
+HYPER_TOY = {
+    'hyper': {'name': 'mlp_layer_code_generator', 'latent_size': 8, 'mlp_dims': [24, 32, 48], 'bias': True, 'sn_coeff': 3.0,
+              'layer_code_generator': {
+                  'name': 'layer_generator', 'code_size': 12,
+                  'default_generators': {
+                      'linear': {'name': 'mlp_layer_generator', 'input_size': 12, 'mlp_dims': [14, 28], 'norm_last': True,
+                                 'affine_last': True, 'bias': True, 'sn_coeff': 5.0},
+                      'final_linear': {'name': 'mlp_layer_generator', 'input_size': 12, 'mlp_dims': [32, 48],
+                                       'norm_last': False, 'norm_before_last': False, 'affine_last': True, 'bias': True,
+                                       'sn_coeff': 5.0}},
+                  'target': {'name': 'mlp', 'activation': 'crater',
+                             'layers': [{'in': 2, 'out': 30}, {'in': 30, 'out': 40}, {'in': 40, 'out': 30},
+                                        {'in': 30, 'out': 4, 'last': True}]}}},
+    'method': {'name': 'repulsive_kernel', 'num': 6, 'gamma': 2.0, 'gamma_ood': 22.0, 'warmup': 300, 'beta_ind': 2.0,
+               'beta_ood': 2.0, 'model_kernel': layers(TOY_RBF, TOY_W), 'model_kernel_ood': layers(TOY_RBF_OOD, TOY_W),
+               'ind_loss': {'name': 'cross_entropy'}},
+}
+
+
+def run_hyper_toy_step(dtype, tag):
+    """configs/toy/fourclass/hyper/mlp.yml as shipped (6 members, 12 inlier + 5 outlier points): list-valued mlp_dims,
+    a FinalLinear generator without output norm, rbf-kernel HE on inliers and outliers (no detach_diag on the outlier
+    kernel, no OOD prediction loss), warm-up factor < 1."""
+    _hyper_step(HYPER_TOY, 'hyper_toy_train_step', dtype, tag, members=6, latent=8, xshape=(17, 2), n_in=12, classes=4,
+                step=120, seed=64, has_ood_loss=False)
+
+
 def run_hyper_step(dtype, tag):
+    """configs/mnist/hyper/mlp-he.yml (see _hyper_step)."""
+    _hyper_step(HYPER, 'hyper_train_step', dtype, tag, members=4, latent=38, xshape=(14, 1, 28, 28), n_in=10, classes=10,
+                step=1500, seed=63, has_ood_loss=True)
+
+
+def _hyper_step(CFG, name, dtype, tag, members, latent, xshape, n_in, classes, step, seed, has_ood_loss):
     """One training step of configs/mnist/hyper/mlp-he.yml (the `hyper:` and `method:` sections as shipped, 4 members)
     with the REAL reference: latent -> code mixer MLP -> layer generators (spectral-norm Linear + GroupNorm + GELU)
     -> LeNet-5 parameters -> batched forward on 10 inlier + 4 outlier images -> RepulsiveKernel loss (cossim HE on
     inliers and outliers, OOD entropy, L2 on the generated weights) -> backward.  Records the generated parameters,
     a digest of every hypernetwork gradient and the power-iteration buffers after the step; the hypernetwork's state is
     the deterministic fill of tests/golden/fill.py (70 M weights are not committed)."""
-    import hyper.target.lenet  # noqa: F401
+    import hyper.target.lenet, hyper.target.mlp  # noqa: F401,E401
     from hyper.generators.base import build_generator
     import hyper.generators.mlp  # noqa: F401
     import hyper.layers.generators  # noqa: F401
@@ -333,38 +369,42 @@ def run_hyper_step(dtype, tag):
     from hyper.diversity import kernels as rk
     from hyper.util.collections import flatten_keys
     rk.KERN_PARAMS['cossim'] = {'eps': 1e-6}
-    torch.manual_seed(63)
-    hyper = build_generator(HYPER['hyper']).to(dtype)
-    method = build_method(HYPER['method']).to(dtype)
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    torch.manual_seed(seed)
+    hyper = build_generator(CFG['hyper']).to(dtype)
+    method = build_method(CFG['method']).to(dtype)
     hyper.train()
     gen = torch.Generator().manual_seed(10)
-    Z = torch.randn(4, 38, generator=gen, dtype=torch.float64).to(dtype)
-    X = torch.randn(14, 1, 28, 28, generator=gen, dtype=torch.float64).to(dtype)
-    Y = torch.randint(0, 10, (10,), generator=gen)
+    ood = xshape[0] - n_in
+    Z = torch.randn(members, latent, generator=gen, dtype=torch.float64).to(dtype)
+    X = torch.randn(*xshape, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, classes, (n_in,), generator=gen)
     sys.path.insert(0, OUT)
     from fill import fill_state, grad_digest, state_stats
     stats = state_stats(hyper)
     fill_state(hyper, stats)
-    rec = {'config': json.dumps(HYPER), 'Z': Z.numpy(), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 1500, 'ood_N': 4,
+    rec = {'config': json.dumps(CFG), 'Z': Z.numpy(), 'X': X.numpy(), 'Y': Y.numpy(), 'step': step, 'ood_N': ood, 'seed': seed,
            'stats': json.dumps(stats), 'state_keys': json.dumps(list(hyper.state_dict().keys()))}
     trainer = types.SimpleNamespace(training=True)
     params = hyper.forward_params(Z)
-    track = hyper(params=params, x=X, sample_params=False, ret_params=True, feature_split=True, ood_N=4)
-    track = method(trainer, track['params'], [], track, X[:10], Y, step=1500)
+    track = hyper(params=params, x=X, sample_params=False, ret_params=True, feature_split=True, ood_N=ood)
+    track = method(trainer, track['params'], [], track, X[:n_in], Y, step=step)
     track['loss'].backward()
     for k, v in flatten_keys(params).items():
         rec['p:' + k] = v.detach().numpy()
     rec.update({'loss': track['loss'].detach().numpy(), 'ind_loss': track['ind_loss'].detach().numpy(),
-                'ood_loss': track['ood_loss'].detach().numpy(), 'ind_rep_loss': track['ind_rep_loss'].detach().numpy(),
+                'ind_rep_loss': track['ind_rep_loss'].detach().numpy(),
                 'ood_rep_loss': track['ood_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy(),
                 'feat_keys': json.dumps(list(track['feats_ind'].keys()))})
+    if has_ood_loss:
+        rec['ood_loss'] = track['ood_loss'].detach().numpy()
     for k, v in hyper.state_dict().items():
         if k.endswith(('weight_u', 'weight_v', 'weight_sigma')):
             rec['after:' + k] = v.numpy()
     for k, v in hyper.named_parameters():
         rec['g:' + k] = grad_digest(k, v.grad)
-    np.savez_compressed(os.path.join(OUT, 'hyper_train_step_%s.npz' % tag), **rec)
-    print('hyper_train_step', tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']),
+    np.savez_compressed(os.path.join(OUT, '%s_%s.npz' % (name, tag)), **rec)
+    print(name, tag, 'loss', float(track['loss']), 'rep', float(track['ind_rep_loss']),
           float(track['ood_rep_loss']), 'keys', len(hyper.state_dict()))
 
 
@@ -401,6 +441,7 @@ def main():
     mk = _import_reference()
     if '--hyper-only' in sys.argv:
         run_hyper_step(torch.float64, 'f64')
+        run_hyper_toy_step(torch.float64, 'f64')
         return
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         run_train_step(dtype, tag)
@@ -408,6 +449,7 @@ def main():
     run_resnet_step(torch.float64, 'f64')
     run_svgd_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
+    run_hyper_toy_step(torch.float64, 'f64')
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)
