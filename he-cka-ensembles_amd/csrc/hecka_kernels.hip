@@ -1958,6 +1958,131 @@ __global__ __launch_bounds__(256) void crater_maxpool2_kernel(const float* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Direct convolution for FEW channels (LeNet-5: 1 -> 6 -> 16, 5x5).  As a GEMM these are [6 x 25] and [16 x 150] weight
+// matrices against hundreds of thousands of patch columns: a 64-row MFMA tile is 75-90 % padding and the patch matrix
+// (2 GB at 128 members x 400 images) is pure HBM traffic.  Here one thread owns one output position and all O <= OT
+// output channels; the weights of tap (c, i, j) are OT consecutive floats at a wave-uniform address (scalar loads, the
+// FMA takes them from SGPRs), x comes through L1 (neighbouring lanes / taps overlap).  unit stride, no dilation.
+// The input gradient is the same kernel on dy with the rotated weights and pad' = k - 1 - pad.
+// ------------------------------------------------------------------------------------------
+template <int KH, int KW, int OT>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restrict__ x, long long xsm,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          float bscale, float* __restrict__ y, int N, int C, int H, int W,
+                                                          int O, int Ho, int Wo, int pad) {
+  const int m = blockIdx.y;
+  const int pos = blockIdx.x * 256 + threadIdx.x;      // the host checks N * Ho * Wo < 2^31 - 256
+  const int HWo = Ho * Wo;
+  if (pos >= N * HWo) return;
+  const int n = pos / HWo, hw = pos - n * HWo;
+  const int h = hw / Wo - pad, w = hw - (hw / Wo) * Wo - pad;
+  float acc[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) acc[o] = 0.f;
+  const float* xn = x + (long long)m * xsm + (long long)n * C * H * W;
+  const float* wm = wt + (long long)m * C * (KH * KW * OT);
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xn + (long long)c * H * W;
+    const float* wc = wm + c * (KH * KW * OT);
+#pragma unroll 1
+    for (int i = 0; i < KH; ++i) {      // one kernel row per trip: KW * OT weights in SGPRs at a time
+      const int hh = h + i;
+#pragma unroll
+      for (int j = 0; j < KW; ++j) {
+        const int ww = w + j;
+        const float v = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? xc[hh * W + ww] : 0.f;
+        const float* wp = wc + (i * KW + j) * OT;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+      }
+    }
+  }
+  float* yp = y + ((long long)m * N + n) * O * HWo + hw;
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+    if (o < O) yp[(long long)o * HWo] = acc[o] + (bias ? bscale * bias[m * O + o] : 0.f);
+}
+
+// Sum over the 64 lanes of a wave in registers (DPP moves, no LDS round trips); lane 63 holds the total.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define HECKA_DPP(ctrl, rows, bound) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xF, bound))
+  v += HECKA_DPP(0xB1, 0xF, true);    // quad_perm [1,0,3,2]
+  v += HECKA_DPP(0x4E, 0xF, true);    // quad_perm [2,3,0,1]
+  v += HECKA_DPP(0x141, 0xF, true);   // row_half_mirror
+  v += HECKA_DPP(0x140, 0xF, true);   // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += HECKA_DPP(0x142, 0xA, false);  // row_bcast15 into rows 1 and 3
+  v += HECKA_DPP(0x143, 0xC, false);  // row_bcast31 into rows 2 and 3
+#undef HECKA_DPP
+  return v;
+}
+
+// Weight gradient: workgroup = (sample split s, member m, (input channel c, group of OT output channels)); every thread
+// walks output positions with a stride of 256 and keeps the OT x KH*KW partial sums (and OT bias sums) in registers,
+// one block-wide reduction at the end, partials [S][M][O][C][KH*KW] summed in fixed order by the caller.
+template <int KH, int KW, int OT>
+__global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(const float* __restrict__ x, long long xsm,
+                                                                const float* __restrict__ dy, float* __restrict__ dwp,
+                                                                float* __restrict__ dbp, int M, int N, int C, int H, int W,
+                                                                int O, int Ho, int Wo, int pad, int nper) {
+  constexpr int KK = KH * KW;
+  __shared__ float red[4][OT * KK + OT];
+  const int s = blockIdx.x, m = blockIdx.y;
+  const int c = blockIdx.z % C, o0 = (blockIdx.z / C) * OT;
+  const int n0 = s * nper, n1 = min(N, n0 + nper);
+  const int HWo = Ho * Wo;
+  float acc[OT][KK], accb[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    accb[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[o][t] = 0.f;
+  }
+  const int total = (n1 - n0) * HWo;     // the host checks N * Ho * Wo < 2^31
+  for (int p = threadIdx.x; p < total; p += 256) {
+    const int n = n0 + p / HWo, hw = p % HWo;
+    const int h = hw / Wo - pad, w = hw - (hw / Wo) * Wo - pad;
+    const float* xc = x + (long long)m * xsm + ((long long)n * C + c) * H * W;
+    float xv[KK];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+      for (int j = 0; j < KW; ++j) {
+        const int hh = h + i, ww = w + j;
+        xv[i * KW + j] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? xc[hh * W + ww] : 0.f;
+      }
+    const float* dp = dy + (((long long)m * N + n) * O + o0) * HWo + hw;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+      const float g = (o0 + o < O) ? dp[(long long)o * HWo] : 0.f;
+      accb[o] += g;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) acc[o][t] = fmaf(g, xv[t], acc[o][t]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+#pragma unroll
+    for (int t = 0; t <= KK; ++t) {
+      const float v = wave_sum_dpp(t < KK ? acc[o][t < KK ? t : 0] : accb[o]);
+      if (lane == 63) red[wv][t < KK ? o * KK + t : OT * KK + o] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < OT * KK + OT; e += 256) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < OT * KK) {
+      const int o = o0 + e / KK, t = e % KK;
+      if (o < O) dwp[((((long long)s * M + m) * O + o) * C + c) * KK + t] = v;
+    } else {
+      const int o = o0 + (e - OT * KK);
+      if (o < O && c == 0 && dbp) dbp[((long long)s * M + m) * O + o] = v;
+    }
+  }
+}
+
 }  // namespace hecka
 
 using namespace hecka;
@@ -2827,6 +2952,56 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
   hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
                      weight, N, C, S, training, dx, dweight, dbias, y, dres);
   return check_launch("batchnorm_act_bwd");
+}
+
+int hecka_conv_direct_eligible(int C, int O, int KH, int KW) {
+  return (C >= 1 && C <= 16 && O >= 1 && O <= 16 && ((KH == 5 && KW == 5) || (KH == 3 && KW == 3))) ? 1 : 0;
+}
+
+int hecka_conv_direct_f32(const float* x, long long x_member_stride, const float* wt, const float* bias, float bias_scale,
+                          int M, int N, int C, int H, int W, int O, int KH, int KW, int pad, float* y, void* stream) {
+  clear_error();
+  if (!x || !wt || !y) return fail(HECKA_EINVAL, "conv_direct: null pointer%s");
+  if (M <= 0 || M > 65535 || N <= 0 || H <= 0 || W <= 0 || pad < 0) return fail(HECKA_EINVAL, "conv_direct: size out of range%s");
+  if (!hecka_conv_direct_eligible(C, O, KH, KW)) return fail(HECKA_EINVAL, "conv_direct: needs C, O <= 16 and a 5x5 or 3x3 kernel%s");
+  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  if (Ho <= 0 || Wo <= 0) return fail(HECKA_EINVAL, "conv_direct: kernel larger than the padded input%s");
+  if ((long long)N * Ho * Wo > 0x7fffff00LL) return fail(HECKA_EINVAL, "conv_direct: size out of range%s");
+  const long long blocks = ((long long)N * Ho * Wo + 255) / 256;
+  dim3 grid((unsigned)blocks, M);
+  hipStream_t st = (hipStream_t)stream;
+#define HECKA_CD(KH_, KW_, OT_) hipLaunchKernelGGL((conv_direct_kernel<KH_, KW_, OT_>), grid, dim3(256), 0, st, x, x_member_stride, \
+                                                   wt, bias, bias_scale, y, N, C, H, W, O, Ho, Wo, pad)
+  if (KH == 5) { if (O <= 8) HECKA_CD(5, 5, 8); else HECKA_CD(5, 5, 16); }
+  else         { if (O <= 8) HECKA_CD(3, 3, 8); else HECKA_CD(3, 3, 16); }
+#undef HECKA_CD
+  return check_launch("conv_direct");
+}
+
+int hecka_conv_direct_wgrad_f32(const float* x, long long x_member_stride, const float* dy, int M, int N, int C, int H, int W,
+                                int O, int KH, int KW, int pad, int splits, float* dw_partial, float* db_partial,
+                                void* stream) {
+  clear_error();
+  if (!x || !dy || !dw_partial) return fail(HECKA_EINVAL, "conv_direct_wgrad: null pointer%s");
+  if (M <= 0 || M > 65535 || N <= 0 || H <= 0 || W <= 0 || pad < 0 || splits <= 0 || splits > N)
+    return fail(HECKA_EINVAL, "conv_direct_wgrad: size out of range%s");
+  if (!hecka_conv_direct_eligible(C, O, KH, KW)) return fail(HECKA_EINVAL, "conv_direct_wgrad: needs C, O <= 16 and a 5x5 or 3x3 kernel%s");
+  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  if (Ho <= 0 || Wo <= 0) return fail(HECKA_EINVAL, "conv_direct_wgrad: kernel larger than the padded input%s");
+  if ((long long)N * Ho * Wo > 0x7fffffffLL) return fail(HECKA_EINVAL, "conv_direct_wgrad: size out of range%s");
+  const int nper = (N + splits - 1) / splits;
+  if ((long long)(splits - 1) * nper >= N) return fail(HECKA_EINVAL, "conv_direct_wgrad: a split would be empty%s");
+  hipStream_t st = (hipStream_t)stream;
+  // 5x5: 8 output channels per workgroup (200 partial sums per thread); 3x3: 16 (144)
+  const int OT = KH == 5 ? 8 : 16;
+  dim3 grid(splits, M, C * ((O + OT - 1) / OT));
+  if (KH == 5)
+    hipLaunchKernelGGL((conv_direct_wgrad_kernel<5, 5, 8>), grid, dim3(256), 0, st, x, x_member_stride, dy, dw_partial,
+                       db_partial, M, N, C, H, W, O, Ho, Wo, pad, nper);
+  else
+    hipLaunchKernelGGL((conv_direct_wgrad_kernel<3, 3, 16>), grid, dim3(256), 0, st, x, x_member_stride, dy, dw_partial,
+                       db_partial, M, N, C, H, W, O, Ho, Wo, pad, nper);
+  return check_launch("conv_direct_wgrad");
 }
 
 int hecka_crater_f32(const float* x, const float* dy, float* out, long long n, void* stream) {

@@ -84,6 +84,32 @@ def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB
     return Y
 
 
+def _direct_ok(geom, C, O):
+    """Few-channel direct convolution (hecka_conv_direct_f32): unit stride, no dilation, equal zero padding on both axes."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    return (os.environ.get('HECKA_CONV_DIRECT', '1') != '0' and sh == 1 and sw == 1 and dh == 1 and dw == 1 and ph == pw
+            and ph <= kh - 1 and bool(_lib.lib().hecka_conv_direct_eligible(C, O, kh, kw)))
+
+
+def _direct_weights(Wt, outs):
+    """[M, taps, outs] -> zero-padded [M, taps, 8 | 16] (the kernel reads OT consecutive floats per tap)."""
+    OT = 8 if outs <= 8 else 16
+    if outs == OT:
+        return Wt.contiguous()
+    wt = Wt.new_zeros(Wt.shape[0], Wt.shape[1], OT)
+    wt[:, :, :outs] = Wt
+    return wt
+
+
+def _conv_direct(x, x_stride, wt, bias, bias_scale, M, N, C, H, W, O, kh, kw, pad):
+    Ho, Wo = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
+    y = torch.empty((M, N, O, Ho, Wo), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_conv_direct_f32(x.data_ptr(), x_stride, wt.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                float(bias_scale), M, N, C, H, W, O, kh, kw, pad, y.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), 'conv_direct')
+    return y
+
+
 class BatchedConv2d(torch.autograd.Function):
     """y[m] = conv2d(x[m] | x, scale * W[m], bias_scale * b[m]);  x [M,N,C,H,W] or [N,C,H,W] (shared),
     W [M,O,C,kh,kw], b [M,O] | None  ->  y [M,N,O,Ho,Wo].  groups = 1, zero padding."""
@@ -101,6 +127,15 @@ class BatchedConv2d(torch.autograd.Function):
             raise RuntimeError('Conv2d kernel %s is larger than the padded input %s' % ((kh, kw), (H, Wd)))
         K, Q = C * kh * kw, N * Ho * Wo
         has_bias = b is not None
+        ctx.direct = _direct_ok(geom, C, O)
+        if ctx.direct:
+            # few channels (LeNet-5): one thread per output position, weights from scalar registers, no patch matrix
+            wt = _direct_weights((scale * W).permute(0, 2, 3, 4, 1).reshape(M, K, O), O)
+            y = _conv_direct(x5, 0 if shared else N * C * H * Wd, wt, b.contiguous() if has_bias else None, bias_scale,
+                             M, N, C, H, Wd, O, kh, kw, geom[4])
+            ctx.save_for_backward(x5, W, None, None, None)
+            ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
+            return y
         if not has_bias and _conv_x3_ok(geom, M, O, K, N, C, H, Wd):
             # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
             Wf = W.reshape(M, O, K).contiguous()
@@ -142,6 +177,27 @@ class BatchedConv2d(torch.autograd.Function):
         K, Q = C * kh * kw, N * Ho * Wo
         dy = dy.contiguous()
         dx = dW = db = None
+        if ctx.direct:
+            H, Wd, pad = x5.shape[3], x5.shape[4], geom[4]
+            L = _lib.lib()
+            if ctx.needs_input_grad[0]:     # the same kernel on dy with the rotated weights, pad' = k - 1 - pad
+                wr = _direct_weights((scale * W).flip(3, 4).permute(0, 1, 3, 4, 2).reshape(M, O * kh * kw, C), C)
+                dx = _conv_direct(dy, N * O * Ho * Wo, wr, None, 0.0, M, N, O, Ho, Wo, C, kh, kw, kh - 1 - pad)
+                dx = dx.sum(0) if shared else dx
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                groups = C * ((O + 7) // 8 if kh == 5 else (O + 15) // 16)
+                want = max(1, min(N, -(-1024 // (M * groups))))      # about four workgroups per CU
+                splits = -(-N // -(-N // want))
+                dwp = torch.empty((splits, M, O, C, kh * kw), device=dy.device, dtype=torch.float32)
+                dbp = torch.empty((splits, M, O), device=dy.device, dtype=torch.float32) if has_bias else None
+                _lib.check(L.hecka_conv_direct_wgrad_f32(
+                    x5.data_ptr(), 0 if shared else N * C * H * Wd, dy.data_ptr(), M, N, C, H, Wd, O, kh, kw, pad, splits,
+                    dwp.data_ptr(), None if dbp is None else dbp.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                    'conv_direct_wgrad')
+                dW = (scale * dwp.sum(0)).view(W.shape)
+                if has_bias:
+                    db = bias_scale * dbp.sum(0)
+            return dx, dW, db, None, None, None
         dymax = _absmax_rows(dy.view(M, -1), M) if xmax is not None else None
         H, Wd = x5.shape[3], x5.shape[4]
         if ctx.needs_input_grad[0] and dymax is not None and _conv_x3_ok(geom, M, C, O * kh * kw, N, O, H, Wd):

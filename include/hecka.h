@@ -271,6 +271,24 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
                                 const float* save_rstd, const float* weight, int G, int N, int C, long long S,
                                 int training, float* dx, float* dres, float* dweight, float* dbias, void* stream);
 
+/* Direct convolution for FEW channels (hyper/layers/conv.py:492-502 loops F.conv2d over the members; LeNet-5's convs are
+ * 1 -> 6 and 6 -> 16 channels, 5x5): unit stride, no dilation, zero padding `pad` on both axes, C <= 16, O <= 16, kernel
+ * 5x5 or 3x3 (hecka_conv_direct_eligible).  No patch matrix, y written as [M,N,O,Ho,Wo].
+ *   x  [M|1, N, C, H, W]  (x_member_stride = N*C*H*W, or 0 when the members share the input)
+ *   wt [M, C*KH*KW, OT]   weights of tap (c,i,j) for all output channels, OT = 8 if O <= 8 else 16 (zero padded), already
+ *                         multiplied by the layer's weight scale
+ *   y  [M, N, O, Ho, Wo] = conv + bias_scale * bias[m,o]  (bias may be NULL)
+ * The input gradient is the same call on dy with wt built from the rotated weights ([M, O*KH*KW, OT >= C]) and
+ * pad' = KH - 1 - pad.
+ * wgrad: dw_partial [splits, M, O, C, KH*KW], db_partial [splits, M, O] (may be NULL) - partial sums over `splits` groups
+ * of samples, to be summed in order by the caller (deterministic). */
+int hecka_conv_direct_eligible(int C, int O, int KH, int KW);
+int hecka_conv_direct_f32(const float* x, long long x_member_stride, const float* wt, const float* bias, float bias_scale,
+                          int M, int N, int C, int H, int W, int O, int KH, int KW, int pad, float* y, void* stream);
+int hecka_conv_direct_wgrad_f32(const float* x, long long x_member_stride, const float* dy, int M, int N, int C, int H, int W,
+                                int O, int KH, int KW, int pad, int splits, float* dw_partial, float* db_partial,
+                                void* stream);
+
 /* crater activation y = c x (1 + tanh((x + 1) / sqrt 2)) of the target nets (hyper/net/activation.py:8-12; the reference
  * composes it from five elementwise torch ops, each a pass over the tensor).  dy == NULL: out = crater(x); otherwise
  * out = dy * crater'(x).  n elements, 16-byte aligned. */

@@ -892,3 +892,52 @@ def test_crater_kernels_match_torch_expression(shape):
         assert (p - q).abs().max().item() <= 2e-6 * q.abs().max().item()
         assert (x2.grad - ref_in.grad).abs().max().item() <= 4e-6 * ref_in.grad.abs().max().item()
         assert ((x2.grad != 0) == (ref_in.grad != 0)).all()      # the same element of every window took the gradient
+
+
+@pytest.mark.parametrize('case', [
+    dict(M=3, N=5, C=1, O=6, k=5, pad=0, H=28, W=28, shared=True, bias=True),      # LeNet conv1
+    dict(M=4, N=3, C=6, O=16, k=5, pad=0, H=12, W=12, shared=False, bias=True),    # LeNet conv2
+    dict(M=2, N=4, C=3, O=5, k=3, pad=1, H=9, W=7, shared=True, bias=False),
+    dict(M=2, N=3, C=16, O=9, k=3, pad=2, H=6, W=11, shared=False, bias=True),
+    dict(M=2, N=2, C=4, O=16, k=5, pad=4, H=5, W=6, shared=False, bias=False),
+    dict(M=1, N=70, C=2, O=3, k=5, pad=2, H=8, W=8, shared=False, bias=True),
+])
+def test_direct_conv_matches_torch_conv2d(case, monkeypatch):
+    """Few-channel direct convolution (hecka_conv_direct_f32 / _wgrad_f32) against F.conv2d in fp64 per member, forward and
+    all three gradients; and the explicit im2col path (HECKA_CONV_DIRECT=0) on the same inputs."""
+    import torch.nn.functional as F
+    from hyper_amd.layers.conv import BatchedConv2d
+    dev = torch.device('cuda:0')
+    torch.manual_seed(11)
+    M, N, C, O, k, pad = (case[key] for key in ('M', 'N', 'C', 'O', 'k', 'pad'))
+    xs = (N, C, case['H'], case['W']) if case['shared'] else (M, N, C, case['H'], case['W'])
+    x0 = torch.randn(*xs, device=dev)
+    W0 = torch.randn(M, O, C, k, k, device=dev)
+    b0 = torch.randn(M, O, device=dev) if case['bias'] else None
+    scale, bscale = 0.37, 1.3
+    geom = (k, k, 1, 1, pad, pad, 1, 1)
+
+    def run():
+        x, W = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        b = b0.clone().requires_grad_(True) if b0 is not None else None
+        y = BatchedConv2d.apply(x, W, b, scale, bscale, geom)
+        return x, W, b, y
+    x, W, b, y = run()
+    up = torch.randn_like(y)
+    (y * up).sum().backward()
+    x64, W64 = x0.double().requires_grad_(True), W0.double().requires_grad_(True)
+    b64 = b0.double().requires_grad_(True) if b0 is not None else None
+    ref = torch.stack([F.conv2d(x64 if case['shared'] else x64[m], scale * W64[m], None if b64 is None else bscale * b64[m],
+                                padding=pad) for m in range(M)])
+    (ref * up.double()).sum().backward()
+
+    def rel(a, r):
+        return float((a.detach().double() - r.detach()).abs().max() / r.detach().abs().max())
+    assert y.shape == ref.shape and rel(y, ref) <= 2e-6
+    assert rel(x.grad, x64.grad) <= 5e-6 and rel(W.grad, W64.grad) <= 5e-6
+    if b is not None:
+        assert rel(b.grad, b64.grad) <= 5e-6
+    monkeypatch.setenv('HECKA_CONV_DIRECT', '0')
+    x2, W2, b2, y2 = run()
+    (y2 * up).sum().backward()
+    assert rel(y2, ref) <= 1e-5 and rel(W2.grad, W64.grad) <= 2e-5 and rel(x2.grad, x64.grad) <= 2e-5
