@@ -2083,6 +2083,41 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(const float* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// y = W^T u for a row-major W [H, Wd]: the power-iteration step of the hypernetwork's spectral normalisation
+// (hyper/net/spectral.py:92) on its 30840 x 2294 output layer.  rocBLAS runs this shape at 0.4 TB/s; here every lane owns
+// one column (a workgroup reads 1 KB of each row, u[r] is wave-uniform), the rows are split over blockIdx.y and the
+// partial sums are added in fixed order.  HBM-bound: 4 H Wd bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_t_kernel(const float* __restrict__ Wm, const float* __restrict__ u,
+                                                     float* __restrict__ part, int H, int Wd, int rper) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rper, r1 = min(H, r0 + rper);
+  if (c >= Wd) return;
+  const float* p = Wm + (long long)r0 * Wd + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = p[(long long)e * Wd];
+    a0 = fmaf(v[0], u[r], a0); a1 = fmaf(v[1], u[r + 1], a1); a2 = fmaf(v[2], u[r + 2], a2); a3 = fmaf(v[3], u[r + 3], a3);
+    a0 = fmaf(v[4], u[r + 4], a0); a1 = fmaf(v[5], u[r + 5], a1); a2 = fmaf(v[6], u[r + 6], a2); a3 = fmaf(v[7], u[r + 7], a3);
+    p += 8LL * Wd;
+  }
+  for (; r < r1; ++r, p += Wd) a0 = fmaf(p[0], u[r], a0);
+  part[(long long)blockIdx.y * Wd + c] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const float* __restrict__ part, float* __restrict__ y, int S, int Wd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Wd) return;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += part[(long long)s * Wd + c];
+  y[c] = a;
+}
+
 }  // namespace hecka
 
 using namespace hecka;
@@ -3002,6 +3037,31 @@ int hecka_conv_direct_wgrad_f32(const float* x, long long x_member_stride, const
     hipLaunchKernelGGL((conv_direct_wgrad_kernel<3, 3, 16>), grid, dim3(256), 0, st, x, x_member_stride, dy, dw_partial,
                        db_partial, M, N, C, H, W, O, Ho, Wo, pad, nper);
   return check_launch("conv_direct_wgrad");
+}
+
+static int gemv_t_splits(int H, int Wd) {
+  const int colblocks = (Wd + 255) / 256;
+  int S = (1024 + colblocks - 1) / colblocks;          // about four workgroups per CU
+  if (S > (H + 31) / 32) S = (H + 31) / 32;            // at least 32 rows per workgroup
+  return S < 1 ? 1 : S;
+}
+size_t hecka_gemv_t_workspace_bytes(int H, int Wd) {
+  if (H <= 0 || Wd <= 0) return 0;
+  return (size_t)gemv_t_splits(H, Wd) * Wd * sizeof(float);
+}
+int hecka_gemv_t_f32(const float* Wm, const float* u, int H, int Wd, float* y, void* ws, size_t ws_bytes, void* stream) {
+  clear_error();
+  if (!Wm || !u || !y || !ws) return fail(HECKA_EINVAL, "gemv_t: null pointer%s");
+  if (H <= 0 || Wd <= 0) return fail(HECKA_EINVAL, "gemv_t: non-positive size%s");
+  if (ws_bytes < hecka_gemv_t_workspace_bytes(H, Wd)) return fail(HECKA_EINVAL, "gemv_t: workspace too small%s");
+  const int S0 = gemv_t_splits(H, Wd);
+  const int rper = (H + S0 - 1) / S0;
+  const int S = (H + rper - 1) / rper;
+  const int colblocks = (Wd + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemv_t_kernel, dim3(colblocks, S), dim3(256), 0, st, Wm, u, static_cast<float*>(ws), H, Wd, rper);
+  hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3(colblocks), dim3(256), 0, st, static_cast<const float*>(ws), y, S, Wd);
+  return check_launch("gemv_t");
 }
 
 int hecka_crater_f32(const float* x, const float* dy, float* out, long long n, void* stream) {

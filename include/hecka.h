@@ -289,6 +289,12 @@ int hecka_conv_direct_wgrad_f32(const float* x, long long x_member_stride, const
                                 int O, int KH, int KW, int pad, int splits, float* dw_partial, float* db_partial,
                                 void* stream);
 
+/* y [Wd] = W^T u for a row-major W [H, Wd]: the power-iteration step v <- normalize(W^T u) of the hypernetwork's spectral
+ * normalisation (hyper/net/spectral.py:92, `torch.mv(weight_mat.t(), u)`), HBM-bound, deterministic (row splits summed in
+ * fixed order).  ws: hecka_gemv_t_workspace_bytes(H, Wd) bytes of device scratch. */
+size_t hecka_gemv_t_workspace_bytes(int H, int Wd);
+int hecka_gemv_t_f32(const float* W, const float* u, int H, int Wd, float* y, void* ws, size_t ws_bytes, void* stream);
+
 /* crater activation y = c x (1 + tanh((x + 1) / sqrt 2)) of the target nets (hyper/net/activation.py:8-12; the reference
  * composes it from five elementwise torch ops, each a pass over the tensor).  dy == NULL: out = crater(x); otherwise
  * out = dy * crater'(x).  n elements, 16-byte aligned. */

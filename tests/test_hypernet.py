@@ -126,3 +126,18 @@ def test_hypernetwork_train_step_matches_reference(name):
         worst = max(worst, err)
         assert err <= 1e-4, (k, err)
     print('hypernetwork step: worst gradient digest error %.2e' % worst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,Wd', [(30840, 2294), (513, 517), (700, 3), (64, 4096)])
+def test_gemv_t_matches_fp64(H, Wd):
+    """hecka_gemv_t_f32 (power-iteration product W^T u) against the fp64 product."""
+    from hyper_amd.net.spectral import _mv_t
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    W = torch.randn(H, Wd, device=dev)
+    u = torch.randn(H, device=dev)
+    y = _mv_t(W, u)
+    ref = torch.mv(W.double().t(), u.double())
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) <= 2e-6
