@@ -1976,8 +1976,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
   const int pos = blockIdx.x * 256 + threadIdx.x;      // the host checks N * Ho * Wo < 2^31 - 256
   const int HWo = Ho * Wo;
   if (pos >= N * HWo) return;
-  const int n = pos / HWo, hw = pos - n * HWo;
-  const int h = hw / Wo - pad, w = hw - (hw / Wo) * Wo - pad;
+  // positions are enumerated row-major in (h, n, w): a wave then sits in ONE output row of a few neighbouring samples,
+  // so a kernel row that falls into the padding is skipped by the whole wave (input gradient of an unpadded conv: a
+  // third of the rows)
+  const int ho = pos / (N * Wo), rem = pos - ho * (N * Wo);
+  const int n = rem / Wo, wo = rem - n * Wo;
+  const int hw = ho * Wo + wo;
+  const int h = ho - pad, w = wo - pad;
   float acc[OT];
 #pragma unroll
   for (int o = 0; o < OT; ++o) acc[o] = 0.f;
@@ -1989,10 +1994,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 #pragma unroll 1
     for (int i = 0; i < KH; ++i) {      // one kernel row per trip: KW * OT weights in SGPRs at a time
       const int hh = h + i;
+      if ((unsigned)hh >= (unsigned)H) continue;
 #pragma unroll
       for (int j = 0; j < KW; ++j) {
         const int ww = w + j;
-        const float v = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? xc[hh * W + ww] : 0.f;
+        const float v = (unsigned)ww < (unsigned)W ? xc[hh * W + ww] : 0.f;
         const float* wp = wc + (i * KW + j) * OT;
 #pragma unroll
         for (int o = 0; o < OT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
