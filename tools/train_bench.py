@@ -1,7 +1,7 @@
 """Train steps/s of the reference's model configurations (BASELINE.json configs[0..2]) on synthetic data of the dataset's
 shape: FixedEnsembleModel forward -> RepulsiveKernel (cross-entropy + HE-CKA feature repulsion) -> backward -> optimizer.
 
-    python tools/train_bench.py mnist|toy|cifar|hyper [--impl amd|ref] [--steps K] [--members M] [--batch B]
+    python tools/train_bench.py mnist|toy|cifar|hyper|hyper_cifar [--impl amd|ref] [--steps K] [--members M] [--batch B]
 
 --impl amd : hyper_amd on cuda:0 (HIP kernels).
 --impl ref : the real reference on this machine's CPU cores (build container only: needs /root/reference; shims as in
@@ -34,7 +34,7 @@ def configs(members):
     return {
         # configs/mnist/hyper/mlp-he.yml as shipped (BASELINE configs[4]: hypernetwork, members SAMPLED every step; 300 inlier +
         # 100 outlier images per batch)
-        'hyper': dict(members=members or 128, batch=300, ood=100, x=(1, 28, 28), classes=10, opt='adamw', sampled=True,
+        'hyper': dict(members=members or 128, batch=300, ood=100, x=(1, 28, 28), classes=10, opt='adamw', sampled=True, clip=0.05,
                       hyper={'name': 'mlp_layer_code_generator', 'latent_size': 38, 'dim_multiplier': 2.84, 'mlp_dims': 4, 'bias': True, 'sn_coeff': 6.0,
                              'layer_code_generator': {'name': 'layer_generator', 'code_size': 26, 'default_generators': {
                                  'conv2d': {'name': 'mlp_sampled_conv_generator', 'input_size': 26, 'dim_multiplier': 2.755, 'mlp_dims': 1, 'bias': True, 'sn_coeff': 3.0},
@@ -46,6 +46,10 @@ def configs(members):
                       method={'name': 'repulsive_kernel', 'gamma': 10.151, 'gamma_ood': 3.688, 'beta_ood': 0.0673, 'l2_reg': 0.0717, 'warmup': 2075,
                               'model_kernel': hyper_he, 'model_kernel_ood': copy.deepcopy(hyper_he),
                               'ind_loss': {'name': 'cross_entropy'}, 'ood_loss': {'name': 'mean_softmax_entropy'}}),
+        # BASELINE configs[4] names a CIFAR-10 hypernetwork; the reference ships none and its resnet18 cannot be generated
+        # (BatchNorm buffers are "only fixed ensembles"): the MNIST hypernetwork above on CIFAR-shaped input,
+        # LeNet-5 with 3 input channels (flatten 16*5*5)
+        'hyper_cifar': None,
         # configs/mnist/base.yml + ens/he-lin.yml
         'mnist': dict(members=members or 5, batch=300, x=(1, 28, 28), classes=10, opt='adamw',
                       hyper={'name': 'ensemble', 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
@@ -70,18 +74,27 @@ def configs(members):
     }
 
 
+def _with_cifar_hyper(cfgs):
+    c = copy.deepcopy(cfgs['hyper'])
+    c['x'] = (3, 32, 32)
+    c['hyper']['layer_code_generator']['target'] = {'name': 'lenet5', 'in_channels': 3, 'num_classes': 10, 'flatten_dims': 400}
+    cfgs['hyper_cifar'] = c
+    return cfgs
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('config', choices=['mnist', 'toy', 'cifar', 'hyper'])
+    ap.add_argument('config', choices=['mnist', 'toy', 'cifar', 'hyper', 'hyper_cifar'])
     ap.add_argument('--impl', default='amd', choices=['amd', 'ref'])
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--members', type=int, default=0)
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--no-fused', action='store_true', help='torch default (foreach) AdamW instead of the fused kernel')
+    ap.add_argument('--bf16-features', action='store_true', help='tracked features enter the loss as bf16 (BASELINE configs[2])')
     ap.add_argument('--graph', action='store_true', help='capture the step in one HIP graph (hyper_amd.experiments.graphed)')
     args = ap.parse_args()
-    c = configs(args.members)[args.config]
+    c = _with_cifar_hyper(configs(args.members))[args.config]
     M, B = c['members'], args.batch or c['batch']
     if not c.get('sampled'):
         c['hyper']['ensemble_size'] = M
@@ -118,8 +131,17 @@ def main():
     def step(i):
         opt.zero_grad(set_to_none=True)
         track = hyper(params=ids, x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=ood)
+        if args.bf16_features:
+            for key in ('feats_ind', 'feats_ood'):
+                if track.get(key) is not None:
+                    track[key] = type(track[key])((k, v.bfloat16()) for k, v in track[key].items())
         track = method(trainer, track['params'], [], track, X, Y, step=3000 + i)
         track['loss'].backward()
+        if c.get('clip'):     # the YAML's `trainer.clip`, as ParticleMethods.batch_end applies it: a non-finite norm skips the step
+            try:
+                torch.nn.utils.clip_grad_norm_(hyper.parameters(), c['clip'], norm_type=2, error_if_nonfinite=True)
+            except RuntimeError:
+                return track['loss']
         opt.step()
         return track['loss']
 
