@@ -141,3 +141,30 @@ def test_gemv_t_matches_fp64(H, Wd):
     ref = torch.mv(W.double().t(), u.double())
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max() / ref.abs().max()) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_graphed_hypernetwork_step_samples_members_inside_the_capture():
+    """GraphedTrainStep with an int member count: latents are drawn inside the captured step (fresh ones every replay),
+    the spectral-norm buffers keep iterating, the loss stays finite and the weights move."""
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from hyper_amd.experiments.graphed import GraphedTrainStep
+    dev = torch.device('cuda:0')
+    gold = np.load(os.path.join(HERE, 'golden', 'hyper_toy_train_step_f64.npz'))
+    cfg = json.loads(str(gold['config']))
+    torch.manual_seed(5)
+    hyper = build_generator(cfg['hyper']).to(dev).train()
+    method = build_method(cfg['method']).to(dev)
+    opt = torch.optim.AdamW(list(hyper.parameters()) + list(method.parameters()), lr=1e-3, capturable=True)
+    X = torch.randn(40, 2, device=dev)
+    Y = torch.randint(0, 4, (30,), device=dev)
+    step = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=6, step=1000, forward_kwargs={'ood_N': 10})
+    w0 = hyper.code_gen.input.linear.weight_orig.detach().clone()
+    u0 = hyper.code_gen.input.linear.weight_u.clone()
+    losses = [float(step()) for _ in range(4)]
+    assert all(np.isfinite(losses))
+    assert len(set(losses)) == 4                      # new latents every replay
+    assert not torch.equal(w0, hyper.code_gen.input.linear.weight_orig)
+    assert not torch.equal(u0, hyper.code_gen.input.linear.weight_u)
