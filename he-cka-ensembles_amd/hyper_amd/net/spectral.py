@@ -48,7 +48,7 @@ class SpectralLinear(nn.Module):
         self.register_buffer('weight_v', v)
         self.register_buffer('weight_sigma', torch.ones(1))
 
-    def compute_weight(self, do_power_iteration):
+    def _sigma(self, do_power_iteration):
         W, u, v = self.weight_orig, self.weight_u, self.weight_v
         if do_power_iteration:
             with torch.no_grad():
@@ -61,10 +61,17 @@ class SpectralLinear(nn.Module):
             self.weight_sigma.copy_(sigma.detach().reshape(1))
         # soft normalisation: only when sigma exceeds coeff.  Written as the reference writes it (a float32 ones(1)
         # against the 0-dim sigma): under torch's promotion rules the factor is float32 even for float64 weights
-        return W / torch.max(torch.ones(1, device=W.device), sigma / self.coeff)
+        return torch.max(torch.ones(1, device=W.device), sigma / self.coeff)
+
+    def compute_weight(self, do_power_iteration):
+        """The normalised weight itself (what the reference's hook assigns to `module.weight`)."""
+        return self.weight_orig / self._sigma(do_power_iteration)
 
     def forward(self, x):
-        return F.linear(x, self.compute_weight(self.training), self.bias)
+        # linear(x, W / f, b) = linear(x, W) / f + b: the scalar goes on the [members, out] result instead of a pass over
+        # the weight matrix forward and two backward (the MNIST hypernetwork's output layer is 30840 x 2294)
+        y = F.linear(x, self.weight_orig) / self._sigma(self.training)
+        return y if self.bias is None else y + self.bias
 
     def extra_repr(self):
         return 'in_features=%d, out_features=%d, bias=%s, coeff=%g' % (
