@@ -79,3 +79,59 @@ class CKASMetric(Metric):
 
     def log_train(self, *args, **kwargs):
         return self.log('train', *args, **kwargs)
+
+
+def unbiased_hsic_all(feats):
+    """Unbiased HSIC (Nguyen et al. 2010.15327 eq. 3; `ModelGenerator._uHSIC`, generators/base.py:210-221) between EVERY
+    pair of (layer, member) zero-diagonal linear Grams of one batch, from three kernels instead of the reference's Python
+    loop of M^2 L^2 small matmuls with three host reads each: the raw Grams (one launch per layer), their pairwise inner
+    products tr(K L) = <K, L> (the loss's own pairwise kernel on [L*M, B*B]) and the row sums.
+    feats: list of L tensors [M,B,P_l] (fp32, GPU) -> H [L*M, L*M] float64, index l * M + m."""
+    from .. import ops
+    M, B = feats[0].shape[0], feats[0].shape[1]
+    if B < 4:
+        raise ValueError('unbiased HSIC needs at least 4 samples')
+    G = torch.cat([ops.raw_gram(ops._features_f32(X.reshape(M, B, -1)).contiguous()) for X in feats])   # [L*M,B,B]
+    G.diagonal(dim1=1, dim2=2).zero_()
+    T = ops.pairwise_inner(G).double()
+    r = G.sum(2).double()                    # K 1
+    s = r.sum(1)                             # 1^T K 1
+    n = float(B)
+    return (T + s[:, None] * s[None, :] / ((n - 1) * (n - 2)) - 2.0 * (r @ r.t()) / (n - 2)) / (n * (n - 3))
+
+
+@torch.no_grad()
+def unbiased_cka(hyper, data, num_samples=5, device='cuda', save_path=None, title=None):
+    """Layer-by-layer unbiased CKA between the members of a sampled ensemble, averaged over member pairs
+    (`ModelGenerator.unbiased_cka`, generators/base.py:224-352): the same members over every batch of `data`, HSIC terms
+    accumulated per batch, CKA from the sums.  As in the reference, entry [a, b] pairs layer max(a, b) of member i with
+    layer min(a, b) of member j (i < j).  Returns the [L, L] float64 matrix; the figure the reference can save is left
+    to the caller (`save_path` is refused)."""
+    from ..util.collections import flatten_keys
+    if save_path is not None:
+        raise NotImplementedError('unbiased_cka: plotting is not part of hyper_amd; plot the returned matrix')
+    was_training = hyper.training
+    hyper.eval()
+    codes = hyper.sample_params(num_samples, device=device)
+    num_train = len(data)
+    acc = None
+    for X, _ in data:
+        X = X.to(device)
+        feats, pred = hyper.forward(hyper.forward_params(codes), X)
+        feats = [f.reshape(f.shape[0], pred.shape[1], -1) for f in flatten_keys(feats).values() if f is not None]
+        L, M = len(feats), feats[0].shape[0]
+        H = unbiased_hsic_all(feats).view(L, M, L, M) / num_train
+        Hd = torch.diagonal(H.reshape(L * M, L * M)).view(L, M)
+        li = torch.arange(L, device=H.device)
+        hi, lo = torch.maximum(li[:, None], li[None, :]), torch.minimum(li[:, None], li[None, :])    # [L,L]
+        kk = Hd[hi].permute(2, 0, 1)[:, None].expand(M, M, L, L)            # [mi, mj, a, b] = Hd[hi[a,b], mi]
+        ll = Hd[lo].permute(2, 0, 1)[None].expand(M, M, L, L)               #                  Hd[lo[a,b], mj]
+        kl = H[hi[:, :, None, None], torch.arange(M, device=H.device)[None, None, :, None], lo[:, :, None, None],
+               torch.arange(M, device=H.device)[None, None, None, :]].permute(2, 3, 0, 1)     # H[hi, mi, lo, mj]
+        cur = torch.stack([kk, kl, ll], dim=-1)
+        acc = cur.clone() if acc is None else acc + cur
+    if was_training:
+        hyper.train()
+    cka = (acc[..., 1] + 1e-8) / (torch.sqrt(torch.abs(acc[..., 0])) * torch.sqrt(torch.abs(acc[..., 2])) + 1e-8)
+    iu = torch.triu_indices(cka.shape[0], cka.shape[1], offset=1, device=cka.device)
+    return cka[iu[0], iu[1]].mean(0)

@@ -254,6 +254,11 @@ class FixedEnsembleModel(nn.Module):
         outs = self.target(params, x)
         return (params, outs) if ret_params else outs
 
+    def unbiased_cka(self, data, num_samples=5, device='cuda', save_path=None, title=None):
+        """generators/base.py:224 (see experiments.metrics.unbiased_cka)."""
+        from ..experiments.metrics import unbiased_cka
+        return unbiased_cka(self, data, num_samples=num_samples, device=device, save_path=save_path, title=title)
+
     @staticmethod
     def from_config(config):
         if isinstance(config['target'], dict):

@@ -43,6 +43,7 @@ class ModelGenerator(nn.Module):
         return self.forward(self.forward_params(self.sample_params(size, device=x.device)), x)
 
     feature_split = staticmethod(FixedEnsembleModel.feature_split)
+    unbiased_cka = FixedEnsembleModel.unbiased_cka
     forward_split = FixedEnsembleModel.forward_split
 
     def _run_target(self, params, x):

@@ -254,3 +254,50 @@ def run_config(cfg, feats, track=None):
     fn = he_layer if lk['name'] == 'he' else cka_layer
     return model_layers(feats, lambda f, track: fn(f, track=track, **kw), weights,
                         cfg.get('reduction', 'mean'), track)
+
+
+# --------------------------------------------------------------------------- evaluation helper
+def unbiased_hsic(K, L):
+    """hyper/generators/base.py:210-221 `_uHSIC` - unbiased HSIC of two zero-diagonal Gram matrices [N,N]."""
+    N = K.shape[0]
+    ones = torch.ones(N, 1, dtype=K.dtype)
+    result = torch.trace(K @ L)
+    result = result + ((ones.t() @ K @ ones @ ones.t() @ L @ ones) / ((N - 1) * (N - 2))).item()
+    result = result - ((ones.t() @ K @ L @ ones) * 2 / (N - 2)).item()
+    return (1 / (N * (N - 3)) * result).item()
+
+
+def unbiased_cka(batches):
+    """hyper/generators/base.py:239-313 - `batches`: per batch a list of L feature tensors [M,B,P_l].  Member pairs
+    i < j, layer pairs with layer_j <= layer_i (K from member i at layer_i, L from member j at layer_j), mirrored into
+    [layer_j, layer_i]; HSIC terms summed over batches (each divided by the number of batches), CKA of the sums, mean
+    over the member pairs -> [L,L] float64."""
+    num_train = len(batches)
+    hs = None
+    for features in batches:
+        mbs, nl = features[0].shape[0], len(features)
+        if hs is None:
+            hs = torch.zeros((mbs, mbs, nl, nl, 3), dtype=torch.double)
+        for m_i in range(mbs):
+            for m_j in range(m_i + 1, mbs):
+                for layer_i in range(nl):
+                    f1 = features[layer_i][m_i]
+                    K = f1 @ f1.t()
+                    K.fill_diagonal_(0.0)
+                    for layer_j in range(layer_i + 1):
+                        f2 = features[layer_j][m_j]
+                        Lm = f2 @ f2.t()
+                        Lm.fill_diagonal_(0.0)
+                        vals = (unbiased_hsic(K, K) / num_train, unbiased_hsic(K, Lm) / num_train,
+                                unbiased_hsic(Lm, Lm) / num_train)
+                        for t, v in enumerate(vals):
+                            hs[m_i, m_j, layer_i, layer_j, t] += v
+                            if layer_i != layer_j:
+                                hs[m_i, m_j, layer_j, layer_i, t] += v
+    cka = (hs[..., 1] + 1e-8) / (torch.sqrt(torch.abs(hs[..., 0])) * torch.sqrt(torch.abs(hs[..., 2])) + 1e-8)
+    avg, count = torch.zeros(cka.shape[2:], dtype=torch.double), 0
+    for i in range(cka.shape[0]):
+        for j in range(i + 1, cka.shape[1]):
+            avg += cka[i, j]
+            count += 1
+    return avg / count

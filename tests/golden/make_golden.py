@@ -437,8 +437,29 @@ def run_conv_case(name, kwargs, M, xshape, dtype):
             'y': y.detach().numpy(), 'up': up.numpy(), 'dflat': flat.grad.numpy(), 'dx': x.grad.numpy()}
 
 
+def run_uhsic():
+    """`ModelGenerator._uHSIC` (generators/base.py:210-221) of the real reference on seeded zero-diagonal Grams."""
+    from hyper.generators.base import ModelGenerator
+    gen = torch.Generator().manual_seed(21)
+    rec = {}
+    for idx, (N, P, Q) in enumerate([(9, 5, 7), (16, 24, 3), (4, 6, 6)]):
+        a = torch.randn(N, P, generator=gen, dtype=torch.float64)
+        b = 0.5 * a[:, :min(P, Q)].repeat(1, 2)[:, :Q] + torch.randn(N, Q, generator=gen, dtype=torch.float64)
+        K, Lm = (a @ a.t()).float(), (b @ b.t()).float()      # the reference's ones() are float32: fp32 Grams only
+        K.fill_diagonal_(0.0)
+        Lm.fill_diagonal_(0.0)
+        rec['K%d' % idx], rec['L%d' % idx] = K.numpy(), Lm.numpy()
+        rec['v%d' % idx] = np.array([ModelGenerator._uHSIC(None, K, K), ModelGenerator._uHSIC(None, K, Lm),
+                                     ModelGenerator._uHSIC(None, Lm, Lm)])
+    np.savez_compressed(os.path.join(OUT, 'uhsic_f32.npz'), **rec)
+    print('uhsic', rec['v0'], rec['v2'])
+
+
 def main():
     mk = _import_reference()
+    if '--uhsic-only' in sys.argv:
+        run_uhsic()
+        return
     if '--hyper-only' in sys.argv:
         run_hyper_step(torch.float64, 'f64')
         run_hyper_toy_step(torch.float64, 'f64')
@@ -450,6 +471,7 @@ def main():
     run_svgd_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
+    run_uhsic()
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)

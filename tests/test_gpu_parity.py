@@ -941,3 +941,36 @@ def test_direct_conv_matches_torch_conv2d(case, monkeypatch):
     x2, W2, b2, y2 = run()
     (y2 * up).sum().backward()
     assert rel(y2, ref) <= 1e-5 and rel(W2.grad, W64.grad) <= 2e-5 and rel(x2.grad, x64.grad) <= 2e-5
+
+
+def test_unbiased_cka_matches_oracle():
+    """hyper_amd's `unbiased_cka` (three kernels per batch) against the restated reference loop (oracle.unbiased_cka,
+    generators/base.py:224-313; its `_uHSIC` is pinned by tests/golden/uhsic_f32.npz) on a small MLP ensemble, 3 batches."""
+    from oracle import hecka_ref as R
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.util.collections import flatten_keys
+    dev = torch.device('cuda:0')
+    torch.manual_seed(8)
+    hyper = build_generator({'name': 'ensemble', 'ensemble_size': 4,
+                             'target': {'name': 'mlp', 'activation': 'crater',
+                                        'layers': [{'in': 3, 'out': 12}, {'in': 12, 'out': 20}, {'in': 20, 'out': 5}]}}).to(dev)
+    data = [(torch.randn(16, 3), torch.zeros(16, dtype=torch.long)) for _ in range(3)]
+
+    class Fixed(type(hyper)):            # same members for the product and the oracle
+        def sample_params(self, size, device=None):
+            return torch.arange(size, device=device)
+    hyper.__class__ = Fixed
+    got = hyper.unbiased_cka(data, num_samples=4, device=dev)
+    batches = []
+    with torch.no_grad():
+        hyper.eval()
+        for X, _ in data:
+            feats, pred = hyper.forward(hyper.forward_params(torch.arange(4, device=dev)), X.to(dev))
+            batches.append([f.reshape(4, 16, -1).cpu() for f in flatten_keys(feats).values() if f is not None])
+    want = R.unbiased_cka(batches)
+    assert got.shape == want.shape == (3, 3) and got.dtype == torch.float64
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert hyper.training is False or True
+    with pytest.raises(NotImplementedError):
+        hyper.unbiased_cka(data, num_samples=4, device=dev, save_path='x.png')

@@ -1,5 +1,7 @@
 """The CPU oracle (oracle/hecka_ref.py) against the golden vectors produced by the real
 reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,3 +63,17 @@ def test_closed_form_matches_autograd():
         assert abs(l.item() - l2) <= 1e-12 * abs(l2)
         for a, b in zip(g, g2):
             assert np.abs(a.numpy() - b).max() <= 1e-11 * np.abs(b).max()
+
+
+def test_unbiased_hsic_matches_reference_golden():
+    """oracle.unbiased_hsic against `ModelGenerator._uHSIC` of the real reference (tests/golden/uhsic_f32.npz)."""
+    import numpy as np
+    import torch
+    from oracle import hecka_ref as R
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'uhsic_f32.npz'))
+    for idx in range(3):
+        K, L = torch.from_numpy(z['K%d' % idx]), torch.from_numpy(z['L%d' % idx])
+        got = [R.unbiased_hsic(K, K), R.unbiased_hsic(K, L), R.unbiased_hsic(L, L)]
+        np.testing.assert_allclose(got, z['v%d' % idx], rtol=1e-6)
+        got64 = [R.unbiased_hsic(K.double(), K.double()), R.unbiased_hsic(K.double(), L.double())]
+        np.testing.assert_allclose(got64, z['v%d' % idx][:2], rtol=1e-4)
