@@ -53,13 +53,14 @@ def rbf_gram(X, Y=None, param=1.0, median=True, detach_diag=True, readd=True, gr
     """K = exp(-d / (2 h_m)), d = squared distances, h_m = param * median(d_m) / (2 log(B+1)) (no gradient
     through the bandwidth) or param^2 with median=False."""
     _only_self(Y, X)
-    if median_ma is not None or grad_var is not None or detach_right:
-        raise NotImplementedError('EMA bandwidth / grad_var / detach_right rbf variants (SVGD kernels) are not built')
+    if median_ma is not None or grad_var is not None:
+        raise NotImplementedError('EMA bandwidth / grad_var rbf variants are not built')
     if detach_diag and not readd:
         raise NotImplementedError('readd_diag=False (zeroed Gram diagonal) is not built; no shipped config uses it')
     if isinstance(param, torch.Tensor) and param.requires_grad:
         raise NotImplementedError('a learnable rbf `param` is not built')
-    return ops.transformed_gram_ad(X, ops.GramSpec(ops.GRAM_RBF, _scalar(param), median))
+    # detach_right: K(X, X.detach()) - same values, gradient through the left argument only (weight / function SVGD)
+    return ops.transformed_gram_ad(X, ops.GramSpec(ops.GRAM_RBF, _scalar(param), median), left_only=bool(detach_right))
 
 
 def _not_built(name):

@@ -56,3 +56,18 @@ class MeanSoftmaxEntropy(LossFunction):
 
     def forward(self, model_bs, x, pred, gt):
         return -_entropy_prob(F.softmax(pred, dim=-1).mean(0)).mean()
+
+
+@register_loss('inlier_outlier_entropy')
+class InlierOutlierEntropy(LossFunction):
+    """Cross-entropy on the inliers + weight * (negative entropy of the mean softmax on the outliers); takes the forward
+    dictionary (`pred_ind`, `pred_ood`) where the other losses take predictions (losses.py:94-113)."""
+
+    def __init__(self, weight=1.0):
+        super().__init__()
+        self.weight = weight
+        self.ce, self.ood_entropy = BatchedCrossEntropy(), MeanSoftmaxEntropy()
+
+    def forward(self, model_bs, x, forward_data, gt):
+        return (self.ce(model_bs, x, forward_data['pred_ind'], gt)
+                + self.weight * self.ood_entropy(model_bs, x, forward_data['pred_ood'], None))

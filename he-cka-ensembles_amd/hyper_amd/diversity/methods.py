@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ..util.collections import flatten_keys
 from .losses import build_loss
-from .model_kernels import WeightKernelUnsupported, build_model_kernel
+from .model_kernels import WeightKernel, build_model_kernel
 
 AVAILABLE_METHODS = {}
 
@@ -100,17 +100,16 @@ def filter_params(param_dict):
 
 @register_method('svgd')
 class SVGD(ParticleMethods):
-    """Stein variational gradient descent on the particles with a FEATURE-space kernel: the [M,M] matrix of a
-    `model_layers` kernel with `reduction: none` (configs/*/svgd/{cka,he}-*.yml).  Per flat parameter block p:
+    """Stein variational gradient descent on the particles with a FEATURE-space kernel - the [M,M] matrix of a
+    `model_layers` kernel with `reduction: none` (configs/*/svgd/{cka,he}-*.yml) - or a WEIGHT-space kernel (`weight`:
+    rbf / ... Gram of the members' flattened parameters, configs/*/svgd/rbf*.yml).  Per flat parameter block p:
         grad_p = (K @ d(-loss)/dp - dK.sum()/dp) / num         (kde: d(-loss)/dp - (dK.sum()/dp) / K.sum(1))
     and -grad_p is pushed back through the generator.  The kernel matrix and its gradient come from the HIP path
     (ops.diversity_layer with reduce=None: head_bwd takes the all-ones upstream matrix)."""
 
     def __init__(self, num, model_kernel, ind_loss, kde=False, beta_ind=1.0):
         super().__init__(num, model_kernel, ind_loss, beta_ind=beta_ind)
-        if isinstance(model_kernel, WeightKernelUnsupported):
-            raise NotImplementedError('hyper_amd svgd: weight-space kernels are not built (feature-space kernels only)')
-        self.weight_space = False
+        self.weight_space = isinstance(model_kernel, WeightKernel)
         self.kde = kde
 
     @staticmethod
@@ -122,7 +121,10 @@ class SVGD(ParticleMethods):
         all_flat = list(flat_params.values()) + list(shared_params)
         loss = self.beta_ind * track['ind_loss']
         drive = self.grads(-loss, all_flat, retain_graph=True, create_graph=create_graph, allow_unused=True)
-        kern = self.model_kernel(flat_params, track['feats_ind'], track['pred_ind'], track)
+        if self.weight_space:      # the kernel sees ONE flat row per member (methods.py:207-209)
+            kern = self.model_kernel(WeightKernel.flatten_weights(params), track['feats_ind'], track['pred_ind'], track)
+        else:
+            kern = self.model_kernel(flat_params, track['feats_ind'], track['pred_ind'], track)
         kgrads = self.grads(kern, all_flat, retain_graph=True, create_graph=create_graph, allow_unused=True)
         for p, gd, gk in zip(all_flat, drive, kgrads):
             if gd is None:
@@ -149,7 +151,7 @@ class RepulsiveKernel(ParticleMethods):
             self.gamma_ood = nn.Parameter(torch.tensor(gamma_ood, dtype=torch.float32), requires_grad=learnable)
         self.model_kernel_ood = model_kernel_ood
         self.warmup = warmup
-        if isinstance(model_kernel, WeightKernelUnsupported):
+        if isinstance(model_kernel, WeightKernel):
             raise ValueError('Weight kernels are not supported for feature repulsion')
 
     def forward(self, trainer, params, shared_params, track, x, gt, ignore_ood_loss=False, step=0):

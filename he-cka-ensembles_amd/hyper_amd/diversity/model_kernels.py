@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..util.collections import flatten_keys
 from . import cos_from_inner, energy_from_cos, hyperspherical_energy, pairwise_cossim
 from .kernels import KERN_PARAMS, MAPS, batched_gram, center_gram
 from .layer_weighting import LayerWeighting, build_weighting  # noqa: F401
@@ -425,16 +426,36 @@ class ModelLayersKernel(BaseModelKernel):
         return config
 
 
-class WeightKernelUnsupported(BaseModelKernel):
-    """Placeholder type for the reference's `weight` / `function` kernels (SVGD methods, out of scope)."""
+class FunctionKernel(FeatureKernel):
+    """Kernel matrix [M,M] between the members' flattened predictions (model_kernels.py:130-147; function-space SVGD)."""
+
+    def forward(self, params, feats, preds, track, layer=None):
+        return self.batched_kernel(preds, flat_second=False)
 
 
-def _not_built_kernel(name):
-    class _K(WeightKernelUnsupported):
-        def __init__(self, *a, **k):
-            raise NotImplementedError('model kernel `%s` belongs to the SVGD methods and is not built in hyper_amd' % name)
-    return _K
+class WeightKernel(FeatureKernel):
+    """Kernel matrix [M,M] between the members' flattened parameters (model_kernels.py:150-205; weight-space SVGD).
+    BatchNorm running statistics are not parameters (keys with `.norm_buffer.`)."""
+
+    @staticmethod
+    def filter_params(param_dict):
+        return OrderedDict((k, v) for k, v in flatten_keys(param_dict).items() if '.norm_buffer.' not in k)
+
+    @staticmethod
+    def flatten_weights(params):
+        flat, empty = flatten_keys(WeightKernel.filter_params(params), include_empty=True)
+        tensors = list(flat.values())
+        if len(tensors) == 0:
+            raise ValueError('No parameters found in the model')
+        members = tensors[0].shape[0]
+        return {'params': flat, 'empty': empty, 'flat_params': torch.cat([p.reshape(members, -1) for p in tensors], dim=1),
+                'model_bs': members, '__flat__': True}
+
+    def forward(self, params, feats, preds, track, layer=None):
+        if isinstance(params, dict) and '__flat__' not in params:
+            params = self.flatten_weights(params)
+        return self.batched_kernel(params['flat_params'], flat_second=False)
 
 
-AVAILABLE_KERNELS['weight'] = _not_built_kernel('weight')
-AVAILABLE_KERNELS['function'] = _not_built_kernel('function')
+AVAILABLE_KERNELS['weight'] = WeightKernel
+AVAILABLE_KERNELS['function'] = FunctionKernel

@@ -135,3 +135,32 @@ def unbiased_cka(hyper, data, num_samples=5, device='cuda', save_path=None, titl
     cka = (acc[..., 1] + 1e-8) / (torch.sqrt(torch.abs(acc[..., 0])) * torch.sqrt(torch.abs(acc[..., 2])) + 1e-8)
     iu = torch.triu_indices(cka.shape[0], cka.shape[1], offset=1, device=cka.device)
     return cka[iu[0], iu[1]].mean(0)
+
+
+@register_metric('accuracy')
+class AccuracyMetric(Metric):
+    """Accuracy of the member-averaged softmax, spread of the members' own accuracies and a running accuracy for the
+    progress bar (experiments/metrics.py:104-152; the reference counts with torchmetrics and reads one value per member
+    back to the host - here the per-member accuracies are one tensor op and one host read).  Note the reference's `log`
+    takes no `train_test` argument for this metric; neither does this one."""
+
+    def __init__(self, classes, term_track=True):
+        self.classes, self.term_track = classes, term_track
+        self.correct = self.total = 0.0
+
+    def reset(self):
+        self.correct = self.total = 0.0
+
+    @torch.no_grad()
+    def log(self, trainer, model_bs, X, Y, track, *args, **kwargs):
+        pred = track['pred_ind']                                         # [M, B, classes]
+        member_acc = 100.0 * (pred.argmax(-1) == Y[None]).double().mean(1)
+        ens = torch.softmax(pred, dim=-1).mean(0).argmax(-1)
+        hits = ens.eq(Y).sum()
+        vals = torch.cat([member_acc, hits.double().reshape(1)]).tolist()  # one host read
+        res = {'accuracy': 100.0 * vals[-1] / Y.shape[0], 'accuracy_std': float(torch.tensor(vals[:-1], dtype=torch.float64).std(unbiased=False))}
+        if self.term_track:
+            self.total += float(Y.shape[0])
+            self.correct += vals[-1]
+            res['term'] = {'acc': res['accuracy'], 'run_acc': 100.0 * self.correct / self.total}
+        return res

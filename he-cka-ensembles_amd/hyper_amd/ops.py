@@ -706,12 +706,12 @@ class TransformedGram(torch.autograd.Function):
     """Un-fused functional API: X -> K' (cossim / rbf Gram, not centred); backward dK' -> dX."""
 
     @staticmethod
-    def forward(ctx, X, gspec):
+    def forward(ctx, X, gspec, left_only=False):
         _check_features(X)
         X = X.contiguous()
         K, rmean, gdiag, hband = transformed_gram(X, gspec, False)
         ctx.save_for_backward(X, K, gdiag, hband)
-        ctx.gspec = gspec
+        ctx.gspec, ctx.left_only = gspec, bool(left_only)
         return K
 
     @staticmethod
@@ -722,12 +722,18 @@ class TransformedGram(torch.autograd.Function):
         st = _stream()
         W = torch.empty_like(K)
         dX = torch.empty_like(X)
-        _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
+        if ctx.left_only:
+            # K(X, X.detach()) (the reference's `detach_right`): the transform's backward is row-wise - row a of W holds
+            # the coefficients of dX_a - so the un-symmetrised upstream gives exactly the left argument's gradient
+            W.copy_(dK)
+            W.diagonal(dim1=1, dim2=2).zero_()
+        else:
+            _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
         _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(K), None, _p(gdiag), _p(hband), M, B, ctx.gspec.kind, st),
                    'gram_transform_bwd')
         _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
-        return dX, None
+        return dX, None, None
 
 
-def transformed_gram_ad(X, gspec):
-    return TransformedGram.apply(_features_f32(X), gspec)
+def transformed_gram_ad(X, gspec, left_only=False):
+    return TransformedGram.apply(_features_f32(X), gspec, left_only)

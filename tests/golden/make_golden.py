@@ -408,6 +408,43 @@ def _hyper_step(CFG, name, dtype, tag, members, latent, xshape, n_in, classes, s
           float(track['ood_rep_loss']), 'keys', len(hyper.state_dict()))
 
 
+WSVGD_CFG = {
+    'hyper': {'name': 'ensemble', 'ensemble_size': 5, 'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10}},
+    'method': {'name': 'svgd', 'num': 5, 'ind_loss': {'name': 'cross_entropy'},
+               'model_kernel': {'name': 'weight', 'kernel': 'rbf', 'detach_right': True}},
+}
+
+
+def run_wsvgd_step(dtype, tag):
+    """One SVGD update of configs/mnist/svgd/rbf.yml (WEIGHT-space rbf kernel with median bandwidth on the members' 44k
+    flattened LeNet parameters, detach_right) with the REAL reference."""
+    import hyper.target.lenet  # noqa: F401
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    torch.manual_seed(53)
+    hyper = build_generator(WSVGD_CFG['hyper']).to(dtype)
+    method = build_method(WSVGD_CFG['method']).to(dtype)
+    gen = torch.Generator().manual_seed(12)
+    X = torch.randn(12, 1, 28, 28, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 10, (12,), generator=gen)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    kern = method.model_kernel(track['params'], track['feats_ind'], track['pred_ind'], track)
+    rec = {'config': json.dumps(WSVGD_CFG), 'X': X.numpy(), 'Y': Y.numpy(), 'loss': loss.detach().numpy(),
+           'pred': track['pred'].detach().numpy(), 'kern': kern.detach().numpy()}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'wsvgd_step_%s.npz' % tag), **rec)
+    print('wsvgd_step', tag, 'loss', float(loss), 'kern', kern.detach().numpy()[0, :3])
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -460,6 +497,9 @@ def main():
     if '--uhsic-only' in sys.argv:
         run_uhsic()
         return
+    if '--wsvgd-only' in sys.argv:
+        run_wsvgd_step(torch.float64, 'f64')
+        return
     if '--hyper-only' in sys.argv:
         run_hyper_step(torch.float64, 'f64')
         run_hyper_toy_step(torch.float64, 'f64')
@@ -469,6 +509,7 @@ def main():
         run_lenet_step(dtype, tag)
     run_resnet_step(torch.float64, 'f64')
     run_svgd_step(torch.float64, 'f64')
+    run_wsvgd_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
     run_uhsic()

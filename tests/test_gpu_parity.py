@@ -974,3 +974,63 @@ def test_unbiased_cka_matches_oracle():
     assert hyper.training is False or True
     with pytest.raises(NotImplementedError):
         hyper.unbiased_cka(data, num_samples=4, device=dev, save_path='x.png')
+
+
+def test_weight_space_svgd_step_matches_reference_golden():
+    """configs/mnist/svgd/rbf.yml: one SVGD update with the WEIGHT-space rbf kernel (median bandwidth over the members'
+    flattened LeNet parameters, detach_right = gradient through the left argument only) against the update the REAL
+    reference produced (tests/golden/wsvgd_step_f64.npz): kernel matrix, loss, every parameter gradient."""
+    import json
+    import os
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'wsvgd_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    assert method.weight_space
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    kern = method.model_kernel(track['params'], track['feats_ind'], track['pred_ind'], track)
+    assert _relerr(kern.detach().cpu().numpy(), z['kern']) <= 2e-5
+    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+
+
+def test_accuracy_metric_and_inlier_outlier_entropy():
+    """`accuracy` metric (experiments/metrics.py:104-152, torchmetrics multiclass accuracy = fraction of hits) and the
+    `inlier_outlier_entropy` loss (losses.py:94-113) against their definitions in fp64."""
+    import torch.nn.functional as F
+    from hyper_amd.experiments.metrics import build_metric
+    from hyper_amd.diversity.losses import build_loss
+    dev = _dev()
+    torch.manual_seed(4)
+    pred = torch.randn(5, 40, 10, device=dev)
+    Y = torch.randint(0, 10, (40,), device=dev)
+    m = build_metric({'name': 'accuracy', 'classes': 10})
+    res = m.log(None, 5, None, Y, {'pred_ind': pred})
+    accs = [100.0 * float((pred[i].argmax(-1) == Y).double().mean()) for i in range(5)]
+    ens = F.softmax(pred.double(), -1).mean(0).argmax(-1)
+    assert abs(res['accuracy'] - 100.0 * float((ens == Y).double().mean())) < 1e-9
+    assert abs(res['accuracy_std'] - float(np.std(accs))) < 1e-9
+    res2 = m.log(None, 5, None, Y, {'pred_ind': pred})
+    assert abs(res2['term']['run_acc'] - res['accuracy']) < 1e-9
+    m.reset()
+    assert m.total == 0.0
+    loss = build_loss({'name': 'inlier_outlier_entropy', 'weight': 0.7})
+    pood = torch.randn(5, 12, 10, device=dev)
+    got = loss(5, None, {'pred_ind': pred, 'pred_ood': pood}, Y)
+    p = F.softmax(pood.double(), -1).mean(0)
+    want = F.cross_entropy(pred.double().reshape(200, 10), Y.repeat(5)) + 0.7 * (p * torch.log(p + 1e-8)).sum(-1).mean()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
