@@ -10,7 +10,8 @@ import torch.nn as nn
 
 from ..util.collections import flatten_keys
 from .losses import build_loss
-from .model_kernels import WeightKernel, build_model_kernel
+from .model_kernels import FunctionKernel, WeightKernel, build_model_kernel
+from .ssge import SpectralSteinEstimator
 
 AVAILABLE_METHODS = {}
 
@@ -134,6 +135,41 @@ class SVGD(ParticleMethods):
             else:
                 grad = (torch.matmul(kern, gd) - gk) / self.num
             p.backward(inputs=inputs, gradient=-grad, retain_graph=True, create_graph=create_graph)
+        return loss, {}
+
+
+@register_method('function_svgd')
+class FunctionSVGD(ParticleMethods):
+    """SVGD in function space (methods.py:229-306, configs/toy/fourclass/fsvgd/*.yml): the particles are the members'
+    predictions on the batch; update = K (score + prior score) - dK / num, pushed back through the predictions.  The
+    likelihood score is d(-loss / exp_std^2)/dpred; the functional prior's score is estimated (SSGE) from the predictions
+    of `num` members with N(0,1) parameters; K is the `function` kernel (the HIP rbf Gram of [members, samples * classes])."""
+
+    def __init__(self, num, model_kernel, ind_loss, exp_std=1.0, eta=0.05, kde=False):
+        super().__init__(num, model_kernel, ind_loss)
+        if not isinstance(model_kernel, FunctionKernel):
+            raise ValueError('Weight kernels/feature kernels are not supported for function SVGD. Use normal SVGD for that')
+        self.ssge = SpectralSteinEstimator(eta)
+        self.exp_std, self.kde = exp_std, kde
+
+    grads = staticmethod(SVGD.grads)
+
+    def backward(self, trainer, params, shared_params, track, x, gt, retain_graph=False, create_graph=False, inputs=None):
+        flat_params = flatten_keys(params)
+        loss, pred = track['ind_loss'], track['pred_ind']
+        score = self.grads(-loss / (self.exp_std ** 2), pred, retain_graph=True, create_graph=create_graph)[0].reshape(self.num, -1)
+        module = trainer.hyper.module if getattr(trainer, 'ddp', False) else trainer.hyper
+        prior_params = module.forward_params(module.sample_random_params(self.num, device=pred.device), device=pred.device)
+        ood_n = getattr(trainer, 'ood_N', 0)
+        _, pred_prior = module.forward(prior_params, x[:-ood_n] if ood_n > 0 else x)
+        grad_prior = self.ssge.compute_score_gradients(pred.reshape(self.num, -1), pred_prior.reshape(self.num, -1))
+        kern = self.model_kernel(flat_params, track['feats_ind'], pred, track)
+        kgrad = self.grads(kern, pred, retain_graph=True, create_graph=create_graph, allow_unused=True)[0].reshape(self.num, -1)
+        if self.kde:
+            grad = (score + grad_prior) - (kgrad / kern.sum(1, keepdim=True)) / self.num
+        else:
+            grad = torch.matmul(kern, score + grad_prior) - kgrad / self.num
+        pred.backward(gradient=-grad.reshape(pred.shape), retain_graph=retain_graph, create_graph=create_graph)
         return loss, {}
 
 

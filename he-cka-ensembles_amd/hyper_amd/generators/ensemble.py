@@ -184,6 +184,9 @@ class FixedEnsembleModel(nn.Module):
             return cache[key]
         return torch.randperm(self.size, device=device, dtype=torch.long)[:size]
 
+    def sample_random_params(self, size, device=None):
+        return str(size)      # forward_params turns a string into that many N(0,1) members
+
     def forward_params(self, codes, device=None):
         if isinstance(codes, str):                      # "random members": N(0,1) flat rows
             params = DefaultOrderedDict()

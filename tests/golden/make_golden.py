@@ -445,6 +445,60 @@ def run_wsvgd_step(dtype, tag):
     print('wsvgd_step', tag, 'loss', float(loss), 'kern', kern.detach().numpy()[0, :3])
 
 
+FSVGD_CFG = {
+    'hyper': TOY['hyper'],
+    'method': {'name': 'function_svgd', 'num': 6, 'eta': 0.05, 'exp_std': 0.125, 'ind_loss': {'name': 'cross_entropy'},
+               'model_kernel': {'name': 'function', 'detach_right': True, 'kernel': 'rbf'}},
+}
+
+
+def run_fsvgd_step(dtype, tag):
+    """One function-space SVGD update of configs/toy/fourclass/fsvgd/rbf.yml with the REAL reference (6-member toy MLP):
+    likelihood score, SSGE estimate of the functional prior's score from N(0,1) members (their parameters are recorded:
+    the draw is the only random input), rbf `function` kernel with detach_right, gradients pushed through the predictions."""
+    import hyper.target.mlp  # noqa: F401
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    from hyper.util.collections import flatten_keys
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    torch.manual_seed(54)
+    hyper = build_generator(FSVGD_CFG['hyper']).to(dtype)
+    method = build_method(FSVGD_CFG['method']).to(dtype)
+    gen = torch.Generator().manual_seed(13)
+    X = torch.randn(12, 2, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 4, (12,), generator=gen)
+    prior = {}
+    orig = hyper.forward_params
+
+    def recording(codes, device=None):
+        out = orig(codes, device=device)
+        if isinstance(codes, str):
+            for k, v in flatten_keys(out).items():
+                out_v = v.to(dtype)
+                prior[k] = out_v
+            # hand the reference the same values in the working dtype
+            from hyper.util.collections import unflatten_keys
+            return unflatten_keys(collections.OrderedDict((k, prior[k]) for k in prior))
+        return out
+    hyper.forward_params = recording
+    trainer = types.SimpleNamespace(training=True, hyper=hyper, ddp=False, ood_N=0)
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    rec = {'config': json.dumps(FSVGD_CFG), 'X': X.numpy(), 'Y': Y.numpy(), 'loss': loss.detach().numpy(),
+           'pred': track['pred'].detach().numpy()}
+    for k, v in prior.items():
+        rec['prior:' + k] = v.detach().numpy()
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'fsvgd_step_%s.npz' % tag), **rec)
+    print('fsvgd_step', tag, 'loss', float(loss), 'prior keys', list(prior))
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -497,6 +551,9 @@ def main():
     if '--uhsic-only' in sys.argv:
         run_uhsic()
         return
+    if '--fsvgd-only' in sys.argv:
+        run_fsvgd_step(torch.float64, 'f64')
+        return
     if '--wsvgd-only' in sys.argv:
         run_wsvgd_step(torch.float64, 'f64')
         return
@@ -510,6 +567,7 @@ def main():
     run_resnet_step(torch.float64, 'f64')
     run_svgd_step(torch.float64, 'f64')
     run_wsvgd_step(torch.float64, 'f64')
+    run_fsvgd_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
     run_uhsic()

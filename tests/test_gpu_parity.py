@@ -1034,3 +1034,38 @@ def test_accuracy_metric_and_inlier_outlier_entropy():
     p = F.softmax(pood.double(), -1).mean(0)
     want = F.cross_entropy(pred.double().reshape(200, 10), Y.repeat(5)) + 0.7 * (p * torch.log(p + 1e-8)).sum(-1).mean()
     assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+
+
+def test_function_svgd_step_matches_reference_golden():
+    """configs/toy/fourclass/fsvgd/rbf.yml: one function-space SVGD update (likelihood score + SSGE prior score through
+    the rbf `function` kernel, detach_right) against the REAL reference (tests/golden/fsvgd_step_f64.npz).  The N(0,1)
+    prior members are the fixture's (the only random input).  fp32 here against fp64 there (measured 2.6e-7)."""
+    import json
+    import os
+    import types
+    from collections import OrderedDict
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from hyper_amd.util.collections import unflatten_keys
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'fsvgd_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    prior = unflatten_keys(OrderedDict((k[6:], torch.from_numpy(z[k]).float().to(dev)) for k in z.files if k.startswith('prior:')))
+    orig = hyper.forward_params
+    hyper.forward_params = lambda codes, device=None: prior if isinstance(codes, str) else orig(codes, device=device)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    trainer = types.SimpleNamespace(training=True, hyper=hyper, ddp=False, ood_N=0)
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(trainer, track['params'], [], track, X, Y, step=0)
+    loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
+    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    worst = max(_relerr(v.grad.cpu().numpy(), z['g:' + k]) for k, v in hyper.named_parameters())
+    print('function svgd: worst gradient error %.2e' % worst)
+    assert worst <= 2e-5
