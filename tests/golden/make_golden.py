@@ -499,6 +499,61 @@ def run_fsvgd_step(dtype, tag):
     print('fsvgd_step', tag, 'loss', float(loss), 'prior keys', list(prior))
 
 
+def _learned_he(arc_eps):
+    return {'name': 'model_layers',
+            'layer_kernel': {'name': 'he', 'learnable': True, 'eps': 0.025, 'arc_eps': arc_eps,
+                             'feature_kernel': {'name': 'feature', 'kernel': 'rbf'}},
+            'layer_weighting': {'name': 'tensor', 'weights': 4, 'learnable': True}}
+
+
+LEARNED_CFG = {
+    'hyper': TOY['hyper'],
+    'method': {'name': 'repulsive_kernel', 'num': 6, 'ind_loss': {'name': 'cross_entropy'},
+               'ood_loss': {'name': 'mean_softmax_entropy'}, 'gamma': 2.0, 'gamma_ood': 20.0, 'learnable': True,
+               'beta_ind': 2.0, 'beta_ood': 0.5, 'warmup': 8,
+               'model_kernel': _learned_he(0.025), 'model_kernel_ood': _learned_he(0.15)},
+}
+
+
+def run_learned_step(dtype, tag):
+    """configs/toy/fourclass/ens+ood/he-rbf-learned.yml with the REAL reference (6 members, 12 inlier + 5 outlier points,
+    warm-up factor 5/8): learnable eps / arc_eps of both HE kernels, learnable `tensor` layer weights, learnable gamma /
+    gamma_ood - gradients of the ensemble AND of every method parameter."""
+    import hyper.target.mlp  # noqa: F401
+    from hyper.generators.base import build_generator
+    import hyper.generators.ensemble  # noqa: F401
+    from hyper.diversity.methods import build_method
+    from hyper.diversity import kernels as rk
+    rk.KERN_PARAMS['rbf'] = {'param': 1.0}
+    torch.manual_seed(55)
+    hyper = build_generator(LEARNED_CFG['hyper']).to(dtype)
+    method = build_method(LEARNED_CFG['method']).to(dtype)
+    gen = torch.Generator().manual_seed(14)
+    X = torch.randn(17, 2, generator=gen, dtype=torch.float64).to(dtype)
+    Y = torch.randint(0, 4, (12,), generator=gen)
+    with torch.no_grad():      # distinct layer weights
+        for mk in (method.model_kernel, method.model_kernel_ood):
+            mk.layer_weighting.weights.copy_(torch.rand(mk.layer_weighting.weights.shape, generator=gen, dtype=torch.float64) + 0.5)
+    trainer = types.SimpleNamespace(training=True)
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=5)
+    track = method(trainer, track['params'], [], track, X[:12], Y, step=5)
+    track['loss'].backward()
+    rec = {'config': json.dumps(LEARNED_CFG), 'X': X.numpy(), 'Y': Y.numpy(), 'step': 5, 'ood_N': 5,
+           'loss': track['loss'].detach().numpy(), 'ind_rep_loss': track['ind_rep_loss'].detach().numpy(),
+           'ood_rep_loss': track['ood_rep_loss'].detach().numpy(), 'pred': track['pred'].detach().numpy()}
+    for k, v in hyper.state_dict().items():
+        rec['w:' + k] = v.numpy()
+    for k, v in hyper.named_parameters():
+        rec['g:' + k] = v.grad.numpy()
+    for k, v in method.state_dict().items():
+        rec['mw:' + k] = v.numpy()
+    for k, v in method.named_parameters():
+        if v.grad is not None:
+            rec['mg:' + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'learned_step_%s.npz' % tag), **rec)
+    print('learned_step', tag, 'loss', float(track['loss']), [k for k in rec if k.startswith('mg:')])
+
+
 # name -> (Conv2d kwargs, members, input shape (4-D = shared over members), )
 CONV_CASES = {
     'conv_shared_gamma': (dict(in_channels=3, out_channels=5, kernel_size=3, padding=1, act='crater', pooling='max',
@@ -551,6 +606,9 @@ def main():
     if '--uhsic-only' in sys.argv:
         run_uhsic()
         return
+    if '--learned-only' in sys.argv:
+        run_learned_step(torch.float64, 'f64')
+        return
     if '--fsvgd-only' in sys.argv:
         run_fsvgd_step(torch.float64, 'f64')
         return
@@ -568,6 +626,7 @@ def main():
     run_svgd_step(torch.float64, 'f64')
     run_wsvgd_step(torch.float64, 'f64')
     run_fsvgd_step(torch.float64, 'f64')
+    run_learned_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
     run_uhsic()

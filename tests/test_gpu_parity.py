@@ -1069,3 +1069,40 @@ def test_function_svgd_step_matches_reference_golden():
     worst = max(_relerr(v.grad.cpu().numpy(), z['g:' + k]) for k, v in hyper.named_parameters())
     print('function svgd: worst gradient error %.2e' % worst)
     assert worst <= 2e-5
+
+
+def test_learnable_hyperparameters_step_matches_reference_golden():
+    """configs/toy/fourclass/ens+ood/he-rbf-learned.yml (SURVEY.md 8b "State / ownership": `learnable: true` needs gradients
+    w.r.t. eps, arc_eps, layer weights, gamma): one step against the REAL reference (tests/golden/learned_step_f64.npz) -
+    losses, every ensemble gradient and every method-parameter gradient; method state-dict keys equal the reference's."""
+    import json
+    import os
+    import types
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'learned_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    method = build_method(cfg['method'])
+    want_keys = [k[3:] for k in z.files if k.startswith('mw:')]
+    assert list(method.state_dict().keys()) == want_keys
+    method.load_state_dict({k: torch.from_numpy(z['mw:' + k]).float() for k in want_keys})
+    hyper, method = hyper.to(dev), method.to(dev)
+    X = torch.from_numpy(z['X']).float().to(dev)
+    Y = torch.from_numpy(z['Y']).to(dev)
+    ood = int(z['ood_N'])
+    track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=ood)
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X[:-ood], Y, step=int(z['step']))
+    track['loss'].backward()
+    for key in ('loss', 'ind_rep_loss', 'ood_rep_loss'):
+        assert abs(track[key].item() - float(z[key])) <= 2e-5 * abs(float(z[key])), key
+    for k, v in hyper.named_parameters():
+        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+    got = dict(method.named_parameters())
+    for k in [k[3:] for k in z.files if k.startswith('mg:')]:
+        assert got[k].grad is not None, k
+        assert _relerr(got[k].grad.cpu().numpy(), z['mg:' + k]) <= 1e-4, k
