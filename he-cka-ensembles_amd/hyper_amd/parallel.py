@@ -289,3 +289,37 @@ class ShardedModelLayersKernel(torch.nn.Module):
         weights = [float(k.layer_weighting.get_weight(i, len(feats))) for i in range(len(feats))]
         xs = [kerns[i].feature_kernel.flatten(f) for i, f in enumerate(feats.values())]
         return sharded_layers_loss(xs, specs, weights, detach.pop(), k.reduction, self.group, self.backend)
+
+
+class _ScaledLoss(torch.nn.Module):
+    def __init__(self, loss, factor):
+        super().__init__()
+        self.loss, self.factor = loss, factor
+
+    def forward(self, *args, **kwargs):
+        return self.factor * self.loss(*args, **kwargs)
+
+
+def shard_method(method, group=None, backend=None):
+    """Member-sharded TRAINING (last sentence): every rank builds the ensemble with ITS members only
+    (`ensemble_size` = `num` = M / G, all on the full batch) and calls `shard_method` once on its `repulsive_kernel` /
+    `mle` method.  After that rank r's loss is  beta * CE(own members) / G + gamma * rep(ALL members)  and its backward
+    leaves on the local parameters exactly the gradients the unsharded step gives those members: the repulsion term is
+    the sharded kernel (global value, gradients for the local members), the per-member means of the data term and of
+    the L2 term are rescaled from M / G members to M.  No gradient all-reduce exists or is needed - members share no
+    weights - so the only exchange is the Gram column slices inside the kernel.  Unlike the reference's DDP (per-rank
+    sub-batch Grams) the loss is the single-GPU loss.  Member-coupled OOD losses (`mean_softmax_entropy`
+    averages the members' softmax) are refused."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if getattr(method, 'ood_loss', None) is not None:
+        raise NotImplementedError('shard_method: the OOD prediction loss averages over all members; not sharded')
+    for name in ('model_kernel', 'model_kernel_ood'):
+        kern = getattr(method, name, None)
+        if kern is not None and not isinstance(kern, ShardedModelLayersKernel):
+            setattr(method, name, ShardedModelLayersKernel(kern, group, backend))
+    if method.ind_loss is not None and not isinstance(method.ind_loss, _ScaledLoss):
+        method.ind_loss = _ScaledLoss(method.ind_loss, 1.0 / world)
+        if method.l2_reg is not None:
+            method.l2_reg = method.l2_reg / world
+    return method

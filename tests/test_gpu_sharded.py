@@ -100,3 +100,80 @@ def test_ranks_on_one_card_match_unsharded(name, world, mode, tmp_path):
         assert abs(res['loss'].item() - ref.item()) <= RTOL * abs(ref.item())
         for g, x in zip(res['grads'], xs):
             assert _relerr(g.numpy(), x.grad[r * Ml:(r + 1) * Ml].cpu().numpy()) <= RTOL
+
+
+TRAIN_CFG = {
+    'target': {'name': 'lenet5', 'in_channels': 1, 'num_classes': 10},
+    'method': {'name': 'repulsive_kernel', 'gamma': 10.5, 'warmup': 600, 'l2_reg': 0.05, 'ind_loss': {'name': 'cross_entropy'},
+               'model_kernel': {'name': 'model_layers',
+                                'layer_weighting': {'name': 'start_end_linear', 'first_layer': 0.387, 'middle_start': 0.746,
+                                                    'middle_increase': 1.267, 'last_layer': 3.63},
+                                'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031,
+                                                 'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}}}},
+}
+TRAIN_M, TRAIN_B = 6, 16
+
+
+def _train_objects(members, seed_members):
+    """Ensemble holding `seed_members` (global member ids: every member's weights depend on its id only)."""
+    import copy
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    torch.manual_seed(123)
+    full = build_generator({'name': 'ensemble', 'ensemble_size': TRAIN_M, 'target': copy.deepcopy(TRAIN_CFG['target'])})
+    part = build_generator({'name': 'ensemble', 'ensemble_size': members, 'target': copy.deepcopy(TRAIN_CFG['target'])})
+    sd = full.state_dict()
+    part.load_state_dict({k: v[seed_members] for k, v in sd.items()})
+    method = build_method(dict(copy.deepcopy(TRAIN_CFG['method']), num=members))
+    gen = torch.Generator().manual_seed(3)
+    X = torch.randn(TRAIN_B, 1, 28, 28, generator=gen)
+    Y = torch.randint(0, 10, (TRAIN_B,), generator=gen)
+    return part, method, X, Y
+
+
+def _train_step(hyper, method, X, Y, members):
+    import types
+    track = hyper(params=list(range(members)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=700)
+    track['loss'].backward()
+    return track
+
+
+def _train_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hyper_amd.parallel import shard_method
+    dev = torch.device('cuda:0')
+    ml = TRAIN_M // world
+    ids = list(range(rank * ml, (rank + 1) * ml))
+    hyper, method, X, Y = _train_objects(ml, ids)
+    hyper, method = hyper.to(dev), shard_method(method.to(dev))
+    track = _train_step(hyper, method, X.to(dev), Y.to(dev), ml)
+    torch.cuda.synchronize()
+    torch.save({'rep': track['ind_rep_loss'].detach().cpu(), 'grads': {k: v.grad.cpu() for k, v in hyper.named_parameters()}},
+               '%s.%d' % (out, rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_member_sharded_training_step_matches_unsharded(world, tmp_path):
+    """each rank trains ITS members (LeNet-5, full batch) with `shard_method`; the gradients it leaves on
+    its parameters equal the unsharded six-member step's gradients of those members, the repulsion value is the global one."""
+    import torch.multiprocessing as mp
+    dev = torch.device('cuda:0')
+    hyper, method, X, Y = _train_objects(TRAIN_M, list(range(TRAIN_M)))
+    hyper, method = hyper.to(dev), method.to(dev)
+    ref = _train_step(hyper, method, X.to(dev), Y.to(dev), TRAIN_M)
+    want = {k: v.grad.cpu() for k, v in hyper.named_parameters()}
+    out = str(tmp_path / 'train')
+    port = 29700 + (os.getpid() + 7 * world) % 200
+    mp.start_processes(_train_worker, args=(world, port, out), nprocs=world, join=True, start_method='spawn')
+    ml = TRAIN_M // world
+    for r in range(world):
+        res = torch.load('%s.%d' % (out, r), weights_only=True)
+        assert abs(res['rep'].item() - ref['ind_rep_loss'].item()) <= RTOL * abs(ref['ind_rep_loss'].item())
+        for k, g in res['grads'].items():
+            assert _relerr(g.numpy(), want[k][r * ml:(r + 1) * ml].numpy()) <= 2e-5, (r, k)
