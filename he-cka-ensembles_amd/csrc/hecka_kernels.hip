@@ -79,6 +79,8 @@ __global__ __launch_bounds__(512) void colmean16_kernel(const unsigned short* __
   }
 }
 
+constexpr long long kSmallGrid = 384;   // fewer 128-row tiles than this (1.5 per CU): the fp32-MFMA kernels take 64-row tiles
+
 template <bool VEC, bool AMAX>
 __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
                                                       float* __restrict__ sbar, unsigned* __restrict__ xmax) {
@@ -885,18 +887,18 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // (6) dX_m = W_m X_m.  MFMA-bound: 2*B*B*P flop per member.
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool FULL>
+template <bool VEC, bool FULL, int T = 128>
 __global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, float* __restrict__ dX, int tilesN) {
-  using Tile = GemmTile<128, 128, true, VEC, NoPrologue, kBK, FULL>;
+  using Tile = GemmTile<T, T, true, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
   const int m = blockIdx.y;
   NoPrologue pro;
   Tile tile;
-  tile.run(sm, g, g.A + (size_t)m * g.strideA, g.B + (size_t)m * g.strideB, ti * 128, tj * 128, 0, g.K, pro);
+  tile.run(sm, g, g.A + (size_t)m * g.strideA, g.B + (size_t)m * g.strideB, ti * T, tj * T, 0, g.K, pro);
   float* out = dX + (size_t)m * g.rowsA * g.colsB;
   tile.for_each([&](int lr, int lc, float v) {
-    const int row = ti * 128 + lr, col = tj * 128 + lc;
+    const int row = ti * T + lr, col = tj * T + lc;
     if (row < g.rowsA && col < g.colsB) out[(size_t)row * g.colsB + col] = v;
   });
 }
@@ -2211,7 +2213,16 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
                        ntile, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_center_kernel<128, true, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
-  else if (vec)
+  else if (nwg < kSmallGrid) {
+    // a small ensemble / batch (MNIST: 5 members x 300 samples = 30 tiles of 128 on 256 CUs): 64-row tiles, 2.5x the
+    // workgroups, each a quarter of the fp32-MFMA work
+    const int nt = (B + 63) / 64;
+    dim3 grid64(nt * (nt + 1) / 2, M);
+    if (vec)
+      hipLaunchKernelGGL((gram_center_kernel<64, true, false>), grid64, dim3(kThreads), 0, st, g, sbar, C, cvec, nt);
+    else
+      hipLaunchKernelGGL((gram_center_kernel<64, false, false>), grid64, dim3(kThreads), 0, st, g, sbar, C, cvec, nt);
+  } else if (vec)
     hipLaunchKernelGGL((gram_center_kernel<128, true, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
   else
     hipLaunchKernelGGL((gram_center_kernel<128, false, false>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
@@ -3136,7 +3147,14 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
                        tilesN, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
-  else if (vec)
+  else if (nwg < kSmallGrid) {      // few tiles of 128: 64-row tiles instead (see hecka_gram_center_f32)
+    const int tn = (P + 63) / 64;
+    dim3 grid64(((B + 63) / 64) * tn, M);
+    if (vec)
+      hipLaunchKernelGGL((gram_bwd_kernel<true, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn);
+    else
+      hipLaunchKernelGGL((gram_bwd_kernel<false, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn);
+  } else if (vec)
     hipLaunchKernelGGL((gram_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
   else
     hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
