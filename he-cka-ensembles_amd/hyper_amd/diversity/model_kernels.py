@@ -332,15 +332,28 @@ class ModelLayersKernel(BaseModelKernel):
                 key = (X.shape[0], X.shape[1], X.dtype, kerns[i].feature_kernel.detach_diag)
                 groups.setdefault(key, []).append(i)
         best = max(groups.values(), key=len) if groups else []
+        pre = None
         if len(best) < 2 or len(best) > 16 or not ops.multi_gram_eligible([Xs[i] for i in best]):
-            return none
+            # no shared Gram launch (the reference's own batch sizes - 300, 100 - are not interior): the Grams stay one
+            # launch per layer, but heads, head_bwd, gamma and the bound are still ONE launch each for all layers - at
+            # these sizes the step is a chain of few-microsecond kernels, and every launch removed counts
+            loose = {}
+            for i in cand:
+                X = Xs[i]
+                if X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.numel() > 0:
+                    loose.setdefault((X.shape[0], X.shape[1], kerns[i].feature_kernel.detach_diag), []).append(i)
+            best = max(loose.values(), key=len) if loose else []
+            if len(best) < 2 or len(best) > 16 or os.environ.get('HECKA_FUSED_RAGGED', '1') == '0':
+                return none
+            with torch.no_grad():
+                pre = [ops.centered_gram(Xs[i].detach().contiguous(), True) for i in best]
         M = Xs[best[0]].shape[0]
         specs = [kerns[i]._spec() for i in best]
         scales = []
         for i, spec in zip(best, specs):
             count = (M * (M - 1) if spec.remove_diag else M * M) if self.reduction == 'mean' else 1
             scales.append(float(weights[i]) / count if count else float('nan'))
-        res = ops.diversity_layers([Xs[i] for i in best], specs, scales, kerns[best[0]].feature_kernel.detach_diag)
+        res = ops.diversity_layers([Xs[i] for i in best], specs, scales, kerns[best[0]].feature_kernel.detach_diag, pre)
         out, S_all, nsq_all = res[0], res[1], res[2]
         for k, index in enumerate(best):
             layer_track[index]['gram'] = res[3 + k]
