@@ -186,7 +186,7 @@ class BatchedConv2d(torch.autograd.Function):
                 dx = dx.sum(0) if shared else dx
             if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
                 groups = C * ((O + 7) // 8 if kh == 5 else (O + 15) // 16)
-                want = max(1, min(N, -(-1024 // (M * groups))))      # about four workgroups per CU
+                want = max(1, min(N, -(-512 // (M * groups))))      # about two workgroups per CU (254 VGPRs: two fit)
                 splits = -(-N // -(-N // want))
                 dwp = torch.empty((splits, M, O, C, kh * kw), device=dy.device, dtype=torch.float32)
                 dbp = torch.empty((splits, M, O), device=dy.device, dtype=torch.float32) if has_bias else None
