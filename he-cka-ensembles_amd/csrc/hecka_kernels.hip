@@ -551,8 +551,10 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
   if (kend > g.K) kend = g.K;
   NoPrologue pro;
   Tile tile;
-  tile.run(sm, g, g.A, g.B, ti * 64, tj * 64, (int)kbeg, (int)kend, pro);
-  float* out = part + (size_t)z * g.rowsA * g.colsB;
+  // blockIdx.y: layer of a batched call (operand stride g.strideA / g.strideB, 0 in a single call)
+  tile.run(sm, g, g.A + (size_t)blockIdx.y * g.strideA, g.B + (size_t)blockIdx.y * g.strideB, ti * 64, tj * 64, (int)kbeg,
+           (int)kend, pro);
+  float* out = part + ((size_t)blockIdx.y * gridDim.z + z) * g.rowsA * g.colsB;
   const bool any = kend > kbeg;
   tile.for_each([&](int lr, int lc, float v) {
     const int row = ti * 64 + lr, col = tj * 64 + lc;
@@ -2403,12 +2405,34 @@ int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long 
                                     void* stream) {
   clear_error();
   if (!C_all || !S_all || !ws) return fail(HECKA_EINVAL, "pairwise_self_batched: null pointer%s");
-  if (L <= 0 || L > 65535 || M != 64 || K <= 0 || K % 32 != 0 || 64 * K * 4 >= (1ll << 31) || !aligned16(C_all))
-    return fail(HECKA_EINVAL, "pairwise_self_batched: needs M == 64, K %% 32 == 0, 64 K floats < 2 GiB (K = %lld)%s", "", K);
+  if (L <= 0 || L > 65535 || M <= 0 || K <= 0 || K > 0x7fffffffLL - 64)
+    return fail(HECKA_EINVAL, "pairwise_self_batched: size out of range (K = %lld)%s", "", K);
   const int nsplit = pairwise_nsplit(M, M, K);
   if (ws_bytes < (size_t)L * nsplit * M * M * sizeof(float))
     return fail(HECKA_EWORKSPACE, "pairwise_self_batched: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
   hipStream_t st = (hipStream_t)stream;
+  if (M != 64 || K % 32 != 0 || 64 * K * 4 >= (1ll << 31) || !aligned16(C_all)) {
+    // any member count: the LDS-tiled kernel with the layer in blockIdx.y
+    GemmOperands g;
+    g.A = C_all; g.B = C_all;
+    g.strideA = g.strideB = (long long)M * K;
+    g.lda = g.ldb = (int)K;
+    g.rowsA = M; g.colsB = M;
+    g.K = (int)K;
+    const long long ktiles = (K + kBK - 1) / kBK;
+    g.kchunk = (int)(((ktiles + nsplit - 1) / nsplit) * kBK);
+    const bool vec = (K % 4 == 0) && aligned16(C_all);
+    const int tiles = (M + 63) / 64;
+    dim3 grid(tiles * tiles, L, nsplit);
+    if (vec)
+      hipLaunchKernelGGL((pairwise_kernel<true, false>), grid, dim3(kThreads), 0, st, g, (float*)ws, tiles);
+    else
+      hipLaunchKernelGGL((pairwise_kernel<false, false>), grid, dim3(kThreads), 0, st, g, (float*)ws, tiles);
+    if (int rc = check_launch("pairwise_self_batched")) return rc;
+    const int n = M * M;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, nsplit, n, S_all, 1.0f);
+    return check_launch("pairwise_self_batched (reduce)");
+  }
   const long long nsteps = K / 32;
   const int spw = (int)((nsteps + (long long)nsplit * 8 - 1) / ((long long)nsplit * 8));
   hipLaunchKernelGGL(pairwise_self64_kernel, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws);

@@ -346,7 +346,9 @@ class ModelLayersKernel(BaseModelKernel):
             if len(best) < 2 or len(best) > 16 or os.environ.get('HECKA_FUSED_RAGGED', '1') == '0':
                 return none
             with torch.no_grad():
-                pre = [ops.centered_gram(Xs[i].detach().contiguous(), True) for i in best]
+                X0 = Xs[best[0]]      # one buffer for all the Grams: the batched pairwise launch reads it as [L,M,B,B]
+                C_all = torch.empty((len(best), X0.shape[0], X0.shape[1], X0.shape[1]), device=X0.device, dtype=torch.float32)
+                pre = [ops.centered_gram(Xs[i].detach().contiguous(), True, out=C_all[k]) for k, i in enumerate(best)]
         M = Xs[best[0]].shape[0]
         specs = [kerns[i]._spec() for i in best]
         scales = []

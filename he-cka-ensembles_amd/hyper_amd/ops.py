@@ -97,7 +97,7 @@ class _GemmChain:
         cls.last[device.index] = (ev, cur.cuda_stream)
 
 
-def centered_gram(X, return_xmax=False):
+def centered_gram(X, return_xmax=False, out=None):
     """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd.
     `return_xmax` adds xmax [M] = max |X[m]| (a by-product of the column-mean pass) for gram_backward: with it the
     dX GEMM may use the fp16-split arithmetic (include/hecka.h, HECKA_GEMM_AUTO)."""
@@ -110,7 +110,9 @@ def centered_gram(X, return_xmax=False):
     M, B, P = X.shape
     sbar = torch.empty((M, P), device=X.device, dtype=torch.float32)
     xmax = torch.empty((M,), device=X.device, dtype=torch.float32)
-    C = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+    C = out if out is not None else torch.empty((M, B, B), device=X.device, dtype=torch.float32)
+    if tuple(C.shape) != (M, B, B) or C.dtype != torch.float32 or not C.is_contiguous():
+        raise RuntimeError('centered_gram: out must be a contiguous fp32 [M,B,B] tensor')
     cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
     st = _stream()
     _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
@@ -317,7 +319,8 @@ def wbound_batched(A_all, nsq_all, gamma_all):
 
 
 def pairwise_self_batched_eligible(M, K):
-    return M == 64 and K > 0 and K % 32 == 0 and 64 * K * 4 < 2 ** 31
+    """One launch for all layers: the streaming kernel at M == 64, the LDS-tiled one otherwise."""
+    return M > 0 and 0 < K < 2 ** 31 - 64 and M * K * 4 < 2 ** 40
 
 
 def pairwise_self_batched(C_all):

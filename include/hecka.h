@@ -131,8 +131,9 @@ int hecka_head_bwd_batched_f32(const float* S, const float* nsq, int L, int Ma, 
                                const double* scale, const float* up_scalar, float* A, void* stream);
 int hecka_coef_gamma_batched_f32(const float* A, const float* cvec, int L, int Ma, int Mb, int B, float* gamma,
                                  void* stream);
-/* S_all[l] = C_all[l] C_all[l]^T for L layers of M = 64 members in one launch (+ one reduction launch):
- * C_all [L,64,K] contiguous, K % 32 == 0; ws >= L * hecka_pairwise_workspace_bytes(64, 64, K). */
+/* S_all[l] = C_all[l] C_all[l]^T for L layers in one launch (+ one reduction launch): C_all [L,M,K] contiguous;
+ * ws >= L * hecka_pairwise_workspace_bytes(M, M, K).  M == 64 with K % 32 == 0 takes the streaming kernel, any other
+ * shape the LDS-tiled one with the layer in blockIdx.y. */
 int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long K, float* S_all, void* ws,
                                     size_t ws_bytes, void* stream);
 int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamma, int L, int Ma, int Mb, int B,
