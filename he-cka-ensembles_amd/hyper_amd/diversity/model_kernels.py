@@ -343,7 +343,11 @@ class ModelLayersKernel(BaseModelKernel):
                 if X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.numel() > 0:
                     loose.setdefault((X.shape[0], X.shape[1], kerns[i].feature_kernel.detach_diag), []).append(i)
             best = max(loose.values(), key=len) if loose else []
-            if len(best) < 2 or len(best) > 16 or os.environ.get('HECKA_FUSED_RAGGED', '1') == '0':
+            if os.environ.get('HECKA_FUSED_RAGGED', '1') == '0':
+                return none
+            if len(best) < 2:
+                return self._fused_transformed(kerns, flist, layer_track, weights)
+            if len(best) > 16:
                 return none
             with torch.no_grad():
                 X0 = Xs[best[0]]      # one buffer for all the Grams: the batched pairwise launch reads it as [L,M,B,B]
@@ -361,6 +365,38 @@ class ModelLayersKernel(BaseModelKernel):
             layer_track[index]['gram'] = res[3 + k]
             layer_track[index]['gram_inner'] = (S_all[k], nsq_all[k])
         return out, frozenset(best)
+
+    def _fused_transformed(self, kerns, flist, layer_track, weights):
+        """cossim / rbf layers (toy: rbf, the MNIST hypernetwork: cossim) in one autograd node: per-layer Gram + transform
+        launches, ONE pairwise / head / head_bwd launch for all of them."""
+        none = (None, frozenset())
+        total = len(flist)
+        groups = {}
+        for i in range(total):
+            k = kerns[i]
+            if not isinstance(k, _PairwiseHead) or k._spec() is None or isinstance(weights[i], torch.Tensor):
+                continue
+            gs = k.feature_kernel.gram_spec()
+            f = flist[i]
+            if gs is None or gs.kind == ops.GRAM_LINEAR or not f.is_cuda or f.ndim < 3 or f.numel() == 0:
+                continue
+            groups.setdefault((f.shape[0], f.shape[1]), []).append(i)
+        best = max(groups.values(), key=len) if groups else []
+        if len(best) < 2 or len(best) > 16:
+            return none
+        M = flist[best[0]].shape[0]
+        specs = [kerns[i]._spec() for i in best]
+        scales = []
+        for i, spec in zip(best, specs):
+            count = (M * (M - 1) if spec.remove_diag else M * M) if self.reduction == 'mean' else 1
+            scales.append(float(weights[i]) / count if count else float('nan'))
+        res = ops.diversity_layers([FeatureKernel.flatten(flist[i]) for i in best], specs, scales, True, None,
+                                   [kerns[i].feature_kernel.gram_spec() for i in best])
+        S_all, nsq_all = res[1], res[2]
+        for k, index in enumerate(best):
+            layer_track[index]['gram'] = res[3 + k]
+            layer_track[index]['gram_inner'] = (S_all[k], nsq_all[k])
+        return res[0], frozenset(best)
 
     def forward(self, params, feats, pred, track):
         total = len(feats)

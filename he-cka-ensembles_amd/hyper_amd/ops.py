@@ -356,9 +356,25 @@ class DiversityLayers(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, *Xs):
-        specs, scales, detach_diag, pre = cfg
+        specs, scales, detach_diag, pre, gspecs = cfg
         Ln, M = len(Xs), Xs[0].shape[0]
         Xs = [X.contiguous() for X in Xs]
+        if gspecs is not None:
+            # cossim / rbf Grams: one raw Gram + transform per layer into a shared [L,M,B,B] buffer; pairwise and heads batched
+            B = Xs[0].shape[1]
+            C_all = torch.empty((Ln, M, B, B), device=Xs[0].device, dtype=torch.float32)
+            aux = [transformed_gram(X, g, True, out=C_all[k])[1:] for k, (X, g) in enumerate(zip(Xs, gspecs))]
+            Cs = [C_all[k] for k in range(Ln)]
+            S_all = pairwise_self_batched(C_all)
+            nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()
+            totals = head_forward_batched(S_all, nsq_all, 0, specs, scales)
+            ctx.save_for_backward(*Xs, *Cs, *[a[0] for a in aux], *[a[1] for a in aux], *[a[2] for a in aux], S_all, nsq_all)
+            ctx.cfg = (specs, scales, bool(detach_diag), Ln)
+            ctx.gspecs = list(gspecs)
+            ctx.mark_non_differentiable(S_all, nsq_all, *Cs)
+            ctx.set_materialize_grads(False)
+            return (totals.sum(), S_all, nsq_all) + tuple(Cs)
+        ctx.gspecs = None
         if pre is None:
             pre = centered_gram_multi(Xs)
         Cs = [p[0] for p in pre]
@@ -380,6 +396,14 @@ class DiversityLayers(torch.autograd.Function):
     def backward(ctx, dout, *_unused):
         specs, scales, detach_diag, Ln = ctx.cfg
         t = ctx.saved_tensors
+        if ctx.gspecs is not None:
+            Xs, Cs, rmeans, gdiags, hbands = (t[k * Ln:(k + 1) * Ln] for k in range(5))
+            S_all, nsq_all = t[5 * Ln:]
+            if dout is None:
+                return (None,) + tuple(torch.zeros_like(X) for X in Xs)
+            A_all = head_backward_batched(S_all, nsq_all, 0, specs, dout.contiguous().float(), scales)
+            return (None,) + tuple(transformed_gram_backward(A_all[li], Cs[li], rmeans[li], gdiags[li], hbands[li], Xs[li],
+                                                             ctx.gspecs[li]) for li in range(Ln))
         Xs, Cs, xmaxs = t[:Ln], t[Ln:2 * Ln], t[2 * Ln:3 * Ln]
         cv_all, S_all, nsq_all = t[3 * Ln:]
         if dout is None:
@@ -395,8 +419,12 @@ class DiversityLayers(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def diversity_layers(Xs, specs, scales, detach_diag=True, pre=None):
-    return DiversityLayers.apply((list(specs), [float(x) for x in scales], bool(detach_diag), pre), *Xs)
+def diversity_layers(Xs, specs, scales, detach_diag=True, pre=None, gspecs=None):
+    """gspecs: one GramSpec per layer for cossim / rbf Grams (fp32 features), None for the linear path."""
+    if gspecs is not None:
+        Xs = [_features_f32(X) for X in Xs]
+    return DiversityLayers.apply((list(specs), [float(x) for x in scales], bool(detach_diag), pre,
+                                  list(gspecs) if gspecs is not None else None), *Xs)
 
 
 class CenteredGramPairwise(torch.autograd.Function):
@@ -571,8 +599,8 @@ def raw_gram(X):
     return G
 
 
-def transformed_gram(X, gspec, center):
-    """cossim / rbf Gram (row-centred when `center`): returns (C, rmean, gdiag, hband)."""
+def transformed_gram(X, gspec, center, out=None):
+    """cossim / rbf Gram (row-centred when `center`): returns (C, rmean, gdiag, hband).  out: [M,B,B] buffer for C."""
     L = _lib.lib()
     M, B, _ = X.shape
     G = raw_gram(X)
@@ -583,7 +611,9 @@ def transformed_gram(X, gspec, center):
             _lib.check(L.hecka_rbf_bandwidth_f32(_p(G), M, B, gspec.param, _p(hband), st), 'rbf_bandwidth')
         else:
             hband.fill_(gspec.param ** 2)
-    C = torch.empty_like(G)
+    C = out if out is not None else torch.empty_like(G)
+    if tuple(C.shape) != tuple(G.shape) or C.dtype != torch.float32 or not C.is_contiguous():
+        raise RuntimeError('transformed_gram: out must be a contiguous fp32 [M,B,B] tensor')
     rmean = torch.empty((M, B), device=X.device, dtype=torch.float32)
     gdiag = torch.empty((M, B), device=X.device, dtype=torch.float32)
     _lib.check(L.hecka_gram_transform_f32(_p(G), M, B, gspec.kind, _p(hband), int(bool(center)), _p(C), _p(rmean),
