@@ -53,9 +53,15 @@ def test_registries_hold_the_reference_names():
     from hyper_amd.generators.ensemble import AVAILABLE_GENERATORS
     assert {'linear', 'final_linear', 'conv2d', 'final_conv2d', 'sequential', 'flatten', 'activation', 'mlp', 'lenet5',
             'resnet18', 'resnet', 'resnet_basic_block'} <= set(AVAILABLE_GEN_MODULES)
-    assert {'mle', 'repulsive_kernel', 'svgd'} <= set(AVAILABLE_METHODS)
+    assert {'mle', 'repulsive_kernel', 'svgd', 'function_svgd'} <= set(AVAILABLE_METHODS)
     assert {'feature', 'cka', 'he', 'model_layers', 'weight', 'function'} <= set(AVAILABLE_KERNELS)
-    assert 'ckas' in AVAILABLE_METRICS and 'ensemble' in AVAILABLE_GENERATORS
+    assert {'ckas', 'accuracy'} <= set(AVAILABLE_METRICS)
+    import hyper_amd.generators  # noqa: F401  (registers the hypernetwork generators)
+    from hyper_amd.layers.generators import AVAILABLE_LAYER_GENERATORS
+    from hyper_amd.diversity.losses import AVAILABLE_LOSSES
+    assert {'ensemble', 'layer_generator', 'generated_layer_generator', 'mlp_layer_code_generator'} <= set(AVAILABLE_GENERATORS)
+    assert {'mlp_layer_generator', 'mlp_sampled_conv_generator'} <= set(AVAILABLE_LAYER_GENERATORS)
+    assert {'cross_entropy', 'mean_softmax_entropy', 'inlier_outlier_entropy'} <= set(AVAILABLE_LOSSES)
 
 
 def test_conv_module_shapes_scales_and_errors():
