@@ -79,7 +79,11 @@ __global__ __launch_bounds__(512) void colmean16_kernel(const unsigned short* __
   }
 }
 
-constexpr long long kSmallGrid = 384;   // fewer 128-row tiles than this (1.5 per CU): the fp32-MFMA kernels take 64-row tiles
+// fewer 128-row tiles than this (1.5 per CU): the fp32-MFMA kernels take 64-row tiles
+static long long small_grid() {
+  static const long long v = getenv("HECKA_SMALL_GRID") ? atoll(getenv("HECKA_SMALL_GRID")) : 384;
+  return v;
+}
 
 template <bool VEC, bool AMAX>
 __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
@@ -2215,7 +2219,8 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
                        ntile, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_center_kernel<128, true, true>), grid, dim3(kThreads), 0, st, g, sbar, C, cvec, ntile);
-  else if (nwg < kSmallGrid) {
+  else if (nwg < small_grid() || 5ll * ((B + 63) / 64) * ((B + 63) / 64) <= 16ll * ntile * ntile) {
+    // (or 64-row tiles cover the ragged B x B with at most 0.8 of the padded area of 128-row tiles: B = 300 -> 320^2 vs 384^2)
     // a small ensemble / batch (MNIST: 5 members x 300 samples = 30 tiles of 128 on 256 CUs): 64-row tiles, 2.5x the
     // workgroups, each a quarter of the fp32-MFMA work
     const int nt = (B + 63) / 64;
@@ -3171,7 +3176,8 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
                        tilesN, (int)(M % 8 == 0));
   else if (full)
     hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
-  else if (nwg < kSmallGrid) {      // few tiles of 128: 64-row tiles instead (see hecka_gram_center_f32)
+  else if (nwg < small_grid() || 5ll * ((B + 63) / 64) * ((P + 63) / 64) <= 16ll * tilesM * tilesN) {
+    // few tiles of 128, or at most 0.8 of their padded area: 64-row tiles instead (see hecka_gram_center_f32)
     const int tn = (P + 63) / 64;
     dim3 grid64(((B + 63) / 64) * tn, M);
     if (vec)
