@@ -123,7 +123,7 @@ def main():
     # the hypernetwork); the reference's trainer takes torch's default (foreach)
     opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph, fused=(args.impl == 'amd' and not args.no_fused))
            if c['opt'] == 'adamw'
-           else torch.optim.SGD(params, lr=0.01, momentum=0.9))
+           else torch.optim.SGD(params, lr=0.01, momentum=0.9, fused=(args.impl == 'amd' and not args.no_fused)))
     X = torch.randn(B + ood, *c['x'], device=dev)
     Y = torch.randint(0, c['classes'], (B,), device=dev)
     trainer = types.SimpleNamespace(training=True)
