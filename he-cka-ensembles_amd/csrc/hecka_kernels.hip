@@ -1658,6 +1658,16 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
   return t;
 }
 
+__device__ __forceinline__ double block_max_d(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  return t;
+}
+
 __global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float* __restrict__ x, int N, int C, long long S,
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
                                                             const float* __restrict__ run_mean, const float* __restrict__ run_var,
@@ -1757,7 +1767,10 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
                                                                 int training, float eps, float* __restrict__ y,
                                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                                 float* __restrict__ batch_var,
-                                                                const float* __restrict__ res, int relu) {
+                                                                const float* __restrict__ res, int relu,
+                                                                unsigned* __restrict__ ymax = nullptr) {
+  // ymax (may be NULL): max |y| per group g, one atomic per workgroup - the operand scale of the convolution that
+  // reads y next (saves that layer a pass over y)
   __shared__ double red[4];
   const int c = blockIdx.x, g = blockIdx.y;
   const long long cnt = (long long)N * S;
@@ -1793,6 +1806,7 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
   }
   const float w = weight ? weight[(size_t)g * C + c] : 1.0f, b = bias ? bias[(size_t)g * C + c] : 0.0f;
   const float sc = w * rstd, sh = b - mean * sc;
+  float amax = 0.f;
   for (int n = m.ni; n < N; n += m.ipp) {
     const size_t o = base + (size_t)n * nstride;
     for (int q = m.si; q < m.s4; q += m.tpi) {
@@ -1806,7 +1820,12 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
         for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
       }
       *reinterpret_cast<f32x4*>(y + o + 4 * q) = r;
+      amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
     }
+  }
+  if (ymax) {
+    const double mx = block_max_d((double)amax, red);
+    if (threadIdx.x == 0) atomicMax(ymax + g, __float_as_uint((float)mx));
   }
 }
 
@@ -1815,7 +1834,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ weight, int N, int C, long long S,
                                                                 int training, float* __restrict__ dx, float* __restrict__ dweight,
                                                                 float* __restrict__ dbias, const float* __restrict__ yout,
-                                                                float* __restrict__ dres) {
+                                                                float* __restrict__ dres, unsigned* __restrict__ dxmax = nullptr) {
   // yout (the fused op's output; may be NULL): relu mask, the gradient reaching the normalisation is dy where yout > 0;
   // dres (may be NULL) receives that masked gradient for the residual branch
   __shared__ double red[4];
@@ -1850,6 +1869,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   if (!dx) return;
   const float w = weight ? weight[(size_t)g * C + c] : 1.0f;
   const float k = w * rstd, m1 = training ? (float)(sdy / (double)cnt) : 0.f, m2 = training ? (float)(sdx / (double)cnt) : 0.f;
+  float amax = 0.f;
   for (int n = m.ni; n < N; n += m.ipp) {
     const size_t o = base + (size_t)n * nstride;
     for (int q = m.si; q < m.s4; q += m.tpi) {
@@ -1864,7 +1884,12 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = k * (d[e] - m1 - (v[e] - mean) * rstd * m2);
       *reinterpret_cast<f32x4*>(dx + o + 4 * q) = r;
+      amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
     }
+  }
+  if (dxmax) {      // max |dx| per group: the scale of the convolution whose output gradient this is
+    const double mx = block_max_d((double)amax, red);
+    if (threadIdx.x == 0) atomicMax(dxmax + g, __float_as_uint((float)mx));
   }
 }
 
@@ -3009,29 +3034,37 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
 
 int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
                                 const float* bias, const float* run_mean, const float* run_var, int training, float eps,
-                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, void* stream) {
+                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, float* ymax,
+                                void* stream) {
   clear_error();
   if (!x || !y || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_fwd: null pointer%s");
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_fwd: size out of range%s");
   if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_act_fwd: eval mode needs running statistics%s");
   if (S % 4 != 0 || !aligned16(x) || !aligned16(y) || (res && !aligned16(res)))
     return fail(HECKA_EINVAL, "batchnorm_act_fwd: needs S %% 4 == 0 and 16-byte alignment%s");
+  if (ymax && hipMemsetAsync(ymax, 0, (size_t)G * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return check_launch("batchnorm_act_fwd (memset)");
   hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
-                     run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, res, relu);
+                     run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, res, relu,
+                     reinterpret_cast<unsigned*>(ymax));
   return check_launch("batchnorm_act_fwd");
 }
 
 int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y, const float* save_mean,
                                 const float* save_rstd, const float* weight, int G, int N, int C, long long S,
-                                int training, float* dx, float* dres, float* dweight, float* dbias, void* stream) {
+                                int training, float* dx, float* dres, float* dweight, float* dbias, float* dxmax,
+                                void* stream) {
   clear_error();
   if (!dy || !x || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_bwd: null pointer%s");
+  if (dxmax && !dx) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dxmax needs dx%s");
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_bwd: size out of range%s");
   if (dres && !y) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dres needs the forward output y%s");
   if (S % 4 != 0 || !aligned16(x) || !aligned16(dy) || (y && !aligned16(y)) || (dx && !aligned16(dx)) || (dres && !aligned16(dres)))
     return fail(HECKA_EINVAL, "batchnorm_act_bwd: needs S %% 4 == 0 and 16-byte alignment%s");
+  if (dxmax && hipMemsetAsync(dxmax, 0, (size_t)G * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return check_launch("batchnorm_act_bwd (memset)");
   hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                     weight, N, C, S, training, dx, dweight, dbias, y, dres);
+                     weight, N, C, S, training, dx, dweight, dbias, y, dres, reinterpret_cast<unsigned*>(dxmax));
   return check_launch("batchnorm_act_bwd");
 }
 

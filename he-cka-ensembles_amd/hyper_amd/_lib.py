@@ -51,7 +51,7 @@ SIGNATURES = {
     'hecka_bgemm_x3_eligible': (_i, [_i, _i, _i, _i]),
     'hecka_bgemm_x3_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hecka_bgemm_x3_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, _vp, _i, _vp, _sz, _vp]),
-    'hecka_batchnorm_act_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
+    'hecka_batchnorm_act_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_conv_direct_eligible': (_i, [_i, _i, _i, _i]),
     'hecka_conv_direct_f32': (_i, [_vp, _ll, _vp, _vp, ctypes.c_float, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'hecka_conv_direct_wgrad_f32': (_i, [_vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -59,7 +59,7 @@ SIGNATURES = {
     'hecka_gemv_t_f32': (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     'hecka_crater_f32': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'hecka_crater_maxpool2_f32': (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
-    'hecka_batchnorm_act_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp]),
+    'hecka_batchnorm_act_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_conv_x3_eligible': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'hecka_conv_x3_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp]),
     'hecka_conv_wgrad_x3_eligible': (_i, [_i, _i, _i, _i, _i, _i, _i]),

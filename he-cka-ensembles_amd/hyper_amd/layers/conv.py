@@ -17,6 +17,7 @@ from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 from .. import _lib
 from ..net import activation
 from .linear import _absmax_rows, _bgemm, _bgemm_x3, _x3_eligible
+from .norm import cached_absmax
 from .module import ParametersGroup, register_gen_module
 
 
@@ -139,7 +140,9 @@ class BatchedConv2d(torch.autograd.Function):
         if not has_bias and _conv_x3_ok(geom, M, O, K, N, C, H, Wd):
             # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
             Wf = W.reshape(M, O, K).contiguous()
-            xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
+            xmax = (cached_absmax(x, Mx) if not shared else None)
+            if xmax is None:
+                xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
             wmax = _absmax_rows(Wf.reshape(M, -1), M)
             y = _conv_x3(Wf, x5, M, O, K, 0 if shared else N * C * H * Wd, N, C, H, Wd,
                          _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device), scale, wmax, xmax, 0 if shared else 1)
@@ -198,7 +201,11 @@ class BatchedConv2d(torch.autograd.Function):
                 if has_bias:
                     db = bias_scale * dbp.sum(0)
             return dx, dW, db, None, None, None
-        dymax = _absmax_rows(dy.view(M, -1), M) if xmax is not None else None
+        dymax = None
+        if xmax is not None:
+            dymax = cached_absmax(dy, M)
+            if dymax is None:
+                dymax = _absmax_rows(dy.view(M, -1), M)
         H, Wd = x5.shape[3], x5.shape[4]
         if ctx.needs_input_grad[0] and dymax is not None and _conv_x3_ok(geom, M, C, O * kh * kw, N, O, H, Wd):
             # input gradient as an implicit-GEMM convolution of dy with the rotated weights: no dgrad patch matrix, no col2im

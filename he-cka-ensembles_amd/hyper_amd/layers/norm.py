@@ -78,6 +78,19 @@ class BatchedBatchNorm(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+def tag_absmax(t, amax):
+    """Remember max |t[g]| (a kernel by-product, [G] on the device) on the tensor object; `cached_absmax` gives it to the next
+    consumer as long as the tensor has not been written since."""
+    t._hecka_absmax = (amax, t._version)
+
+
+def cached_absmax(t, rows):
+    tag = getattr(t, '_hecka_absmax', None)
+    if tag is not None and tag[1] == t._version and tag[0].shape[0] == rows and t.shape[0] == rows:
+        return tag[0]
+    return None
+
+
 class BatchedBatchNormAct(torch.autograd.Function):
     """y[m] = [relu](batch_norm(x[m], weight[m], bias[m]) [+ res[m]]) in one launch each way (hecka_batchnorm_act_*): the
     two tails of a ResNet block, norm -> relu and norm -> + shortcut -> relu.  Same by-products as BatchedBatchNorm."""
@@ -93,14 +106,16 @@ class BatchedBatchNormAct(torch.autograd.Function):
         w = weight.contiguous() if weight is not None else None
         b = bias.contiguous() if bias is not None else None
         y = torch.empty_like(x)
+        ymax = torch.empty((M,), device=x.device, dtype=torch.float32)
         mean = torch.empty((M, C), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         var = torch.empty_like(mean) if training else None
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(_lib.lib().hecka_batchnorm_act_fwd_f32(
             x.data_ptr(), ptr(res), M, N, C, S, ptr(w), ptr(b), ptr(run_mean), ptr(run_var), int(training), float(eps),
-            int(bool(relu)), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var),
+            int(bool(relu)), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var), ymax.data_ptr(),
             torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
+        tag_absmax(y, ymax)      # the convolution that reads y next takes its operand scale from here
         ctx.save_for_backward(x, mean, rstd, w, y if relu else None)
         ctx.cfg = (training, S, weight is not None, bias is not None, res is not None)
         if var is None:
@@ -115,6 +130,7 @@ class BatchedBatchNormAct(torch.autograd.Function):
         M, N, C = x.shape[:3]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dxmax = torch.empty((M,), device=x.device, dtype=torch.float32) if dx is not None else None
         dres = None
         if has_res and ctx.needs_input_grad[1]:
             dres = torch.empty_like(x) if y is not None else dy      # no relu: the residual's gradient is dy itself
@@ -123,8 +139,10 @@ class BatchedBatchNormAct(torch.autograd.Function):
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(_lib.lib().hecka_batchnorm_act_bwd_f32(
             dy.data_ptr(), x.data_ptr(), ptr(y), mean.data_ptr(), rstd.data_ptr(), ptr(w), M, N, C, S, int(training),
-            ptr(dx), ptr(dres) if y is not None else None, ptr(dw), ptr(db), torch.cuda.current_stream().cuda_stream),
-            'batchnorm_act_bwd')
+            ptr(dx), ptr(dres) if y is not None else None, ptr(dw), ptr(db), ptr(dxmax),
+            torch.cuda.current_stream().cuda_stream), 'batchnorm_act_bwd')
+        if dx is not None:
+            tag_absmax(dx, dxmax)    # dx is the output gradient of the convolution in front of this norm
         return dx, dres, dw, db, None, None, None, None, None
 
 

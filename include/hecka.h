@@ -264,13 +264,17 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
 
 /* Batched BatchNorm fused with what follows it in a ResNet block (hyper/target/resnet.py:67-74: norm -> relu, and
  * norm -> + shortcut -> relu): y = [relu](batch_norm(x) [+ res]).  Backward takes the forward OUTPUT y as the relu mask
- * (NULL: no relu) and returns the masked gradient for the residual branch in dres (may be NULL).  S % 4 == 0. */
+ * (NULL: no relu) and returns the masked gradient for the residual branch in dres (may be NULL).  S % 4 == 0.
+ * ymax / dxmax [G] (may be NULL): max |y| / max |dx| per group as a by-product - the fp16-split convolution that reads the
+ * tensor next needs exactly that as its operand scale, and would otherwise spend a pass over the tensor on it. */
 int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
                                 const float* bias, const float* run_mean, const float* run_var, int training, float eps,
-                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, void* stream);
+                                int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, float* ymax,
+                                void* stream);
 int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y, const float* save_mean,
                                 const float* save_rstd, const float* weight, int G, int N, int C, long long S,
-                                int training, float* dx, float* dres, float* dweight, float* dbias, void* stream);
+                                int training, float* dx, float* dres, float* dweight, float* dbias, float* dxmax,
+                                void* stream);
 
 /* Direct convolution for FEW channels (hyper/layers/conv.py:492-502 loops F.conv2d over the members; LeNet-5's convs are
  * 1 -> 6 and 6 -> 16 channels, 5x5): unit stride, no dilation, zero padding `pad` on both axes, C <= 16, O <= 16, kernel
