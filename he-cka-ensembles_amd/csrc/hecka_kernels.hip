@@ -2795,7 +2795,8 @@ int hecka_absmax_rows_f32(const float* V, int rows, long long n, float* out, voi
   if (rows <= 0 || rows > 65535 || n <= 0) return fail(HECKA_EINVAL, "absmax_rows: size out of range%s");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(out, 0, (size_t)rows * sizeof(float), st) != hipSuccess) return check_launch("absmax_rows (memset)");
-  const int chunks = (int)std::max<long long>(1, std::min<long long>(n / 65536, 1024 / rows + 1));
+  // 8192 elements (eight 16-byte loads per thread) per workgroup at least, about 1024 workgroups at most
+  const int chunks = (int)std::max<long long>(1, std::min<long long>(n / 8192, 1024 / rows + 1));
   hipLaunchKernelGGL(absmax_rows_kernel, dim3(chunks, rows), dim3(256), 0, st, V, n, chunks, reinterpret_cast<unsigned*>(out));
   return check_launch("absmax_rows");
 }
