@@ -85,6 +85,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('HECKA_BENCH_ONE_CARD') == '1':     # rehearsal of the N > 1 path on a one-GPU box (with gloo below)
+        local = 0
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dist = None
@@ -93,7 +95,11 @@ def main():
         import torch.distributed as dist
         if force_sharded and 'RANK' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('HECKA_BENCH_BACKEND', 'nccl')      # 'nccl' = RCCL; 'gloo' only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from hyper_amd import ops, _lib as _hl
     from hyper_amd.diversity.model_kernels import build_model_kernel
