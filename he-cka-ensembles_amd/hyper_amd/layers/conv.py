@@ -159,7 +159,9 @@ class BatchedConv2d(torch.autograd.Function):
         # tile, scaled by max |x| (the patches are copies of x) and max |W|
         xmax = wmax = None
         if not has_bias and (_x3_eligible(M, O, Q, R) or _x3_eligible(M, O, R, Q) or _x3_eligible(M, K, Q, O)):
-            xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
+            xmax = cached_absmax(x, Mx) if not shared else None
+            if xmax is None:
+                xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
             wmax = _absmax_rows(Wf.reshape(M, -1), M)
         if xmax is not None and _x3_eligible(M, O, Q, R):
             y = _bgemm_x3(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale, wmax, xmax, 0 if shared else 1)
