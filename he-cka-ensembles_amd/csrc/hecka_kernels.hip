@@ -893,12 +893,29 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // (6) dX_m = W_m X_m.  MFMA-bound: 2*B*B*P flop per member.
 // ------------------------------------------------------------------------------------------
+// gate (may be NULL): a device scalar; *gate == 0 means "the upstream gradient of this whole term is exactly zero"
+// (a masked NaN loss term, hyper/diversity/methods.py:342): the tile is zero-filled and W / X are not read, so that
+// 0 * NaN never reaches dX.
+template <typename T>
+__device__ __forceinline__ void zero_tile(T* __restrict__ out, size_t ld, int row0, int col0, int rows, int cols, int TR,
+                                          int TC) {
+  for (int e = threadIdx.x; e < TR * TC; e += blockDim.x) {
+    const int r = row0 + e / TC, c = col0 + e % TC;
+    if (r < rows && c < cols) out[(size_t)r * ld + c] = T(0.f);
+  }
+}
+
 template <bool VEC, bool FULL, int T = 128>
-__global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, float* __restrict__ dX, int tilesN) {
+__global__ __launch_bounds__(kThreads, 2) void gram_bwd_kernel(GemmOperands g, float* __restrict__ dX, int tilesN,
+                                                               const float* __restrict__ gate) {
   using Tile = GemmTile<T, T, true, VEC, NoPrologue, kBK, FULL>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN;
   const int m = blockIdx.y;
+  if (gate && *gate == 0.f) {
+    zero_tile(dX + (size_t)m * g.rowsA * g.colsB, (size_t)g.colsB, ti * T, tj * T, g.rowsA, g.colsB, T, T);
+    return;
+  }
   NoPrologue pro;
   Tile tile;
   tile.run(sm, g, g.A + (size_t)m * g.strideA, g.B + (size_t)m * g.strideB, ti * T, tj * T, 0, g.K, pro);
@@ -937,13 +954,18 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(con
                                                                   const unsigned* __restrict__ wmax,
                                                                   const float* __restrict__ xmax,
                                                                   void* __restrict__ dX, int B, int P, int tilesM,
-                                                                  int tilesN, int xcd_map) {
+                                                                  int tilesN, int xcd_map, const float* __restrict__ gate) {
   using Tile = GemmTileX6<128, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
   member_tile(tilesM * tilesN, xcd_map, m, tl);
   const int ti = tl % tilesM, tj = tl / tilesM;
+  if (gate && *gate == 0.f) {
+    if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * 128, tj * 128, B, P, 128, 128);
+    else zero_tile(static_cast<unsigned short*>(dX) + (size_t)m * B * P, (size_t)P, ti * 128, tj * 128, B, P, 128, 128);
+    return;
+  }
   ScaleProX6<SCHEME> pro;
   pro.sa = SCHEME == 1 ? pow2_scale(__uint_as_float(wmax[m]), 14) : 1.0f;
   pro.sb = SCHEME == 1 ? pow2_scale(xmax[m], 14) : 1.0f;
@@ -2163,7 +2185,7 @@ using namespace hecka;
 
 extern "C" {
 
-int hecka_version(void) { return 4; }
+int hecka_version(void) { return 5; }
 
 static int g_gemm_mode = 0;
 int hecka_set_gemm_mode(int mode) {
@@ -2500,8 +2522,10 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   const bool full = vec && (Ma % 64 == 0) && (N % 128 == 0) && (Mb % kBK == 0);
   unsigned* wm = reinterpret_cast<unsigned*>(wmax);
   if (wm && hipMemsetAsync(wm, 0, (size_t)Ma * sizeof(unsigned), st) != hipSuccess) return check_launch("combine (memset)");
+  // (the streaming kernel addresses C and W through 32-bit buffer offsets: 64 rows of N floats must stay below 4 GiB,
+  // i.e. B < 4096 at 64 members - larger Grams take the tiled kernel)
   if (mode == 1 && Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && N % 64 == 0 && n_start % 64 == 0 && aligned16(A) &&
-      aligned16(C) && aligned16(gamma) && aligned16(W) && !getenv("HECKA_COMBINE_TILED")) {
+      aligned16(C) && aligned16(gamma) && aligned16(W) && 64ll * N * 4 < (1ll << 32) && !getenv("HECKA_COMBINE_TILED")) {
     const char* ge = getenv("HECKA_COMBINE_WGS");
     const unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, ge ? atoi(ge) : 512));
     if (Ma == 64)
@@ -3175,8 +3199,8 @@ int hecka_crater_maxpool2_f32(const float* x, const float* dy, float* out, long 
   return check_launch("crater_maxpool2");
 }
 
-int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,
-                       float* dX, void* stream) {
+int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, const float* gate, int M, int B,
+                       int P, float* dX, void* stream) {
   clear_error();
   if (!W || !X || !dX) return fail(HECKA_EINVAL, "gram_bwd: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "gram_bwd: bad size%s");
@@ -3201,34 +3225,34 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
   // tools/grad_margin.py, tools/bwd_accuracy.py).  HECKA_BWD_FOLD=1 keeps the local chains.
   if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO && B <= 1024 && !getenv("HECKA_BWD_FOLD"))
     hipLaunchKernelGGL((gram_bwd_x6_kernel<1, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P,
-                       tilesM, tilesN, (int)(M % 8 == 0));
+                       tilesM, tilesN, (int)(M % 8 == 0), gate);
   else if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO)
     hipLaunchKernelGGL(gram_bwd_x6_kernel<1>, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, tilesM,
-                       tilesN, (int)(M % 8 == 0));
+                       tilesN, (int)(M % 8 == 0), gate);
   else if (split_ok)
     hipLaunchKernelGGL(gram_bwd_x6_kernel<0>, dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, tilesM,
-                       tilesN, (int)(M % 8 == 0));
+                       tilesN, (int)(M % 8 == 0), gate);
   else if (full)
-    hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
+    hipLaunchKernelGGL((gram_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, g, dX, tilesN, gate);
   else if (nwg < small_grid() || 5ll * ((B + 63) / 64) * ((P + 63) / 64) <= 16ll * tilesM * tilesN) {
     // few tiles of 128, or at most 0.8 of their padded area: 64-row tiles instead (see hecka_gram_center_f32)
     const int tn = (P + 63) / 64;
     dim3 grid64(((B + 63) / 64) * tn, M);
     if (vec)
-      hipLaunchKernelGGL((gram_bwd_kernel<true, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn);
+      hipLaunchKernelGGL((gram_bwd_kernel<true, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn, gate);
     else
-      hipLaunchKernelGGL((gram_bwd_kernel<false, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn);
+      hipLaunchKernelGGL((gram_bwd_kernel<false, false, 64>), grid64, dim3(kThreads), 0, st, g, dX, tn, gate);
   } else if (vec)
-    hipLaunchKernelGGL((gram_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
+    hipLaunchKernelGGL((gram_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN, gate);
   else
-    hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN);
+    hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN, gate);
   return check_launch("gram_bwd");
 }
 
-int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, int M, int B, int P,
-                       void* dX, void* stream) {
+int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate, int M,
+                       int B, int P, void* dX, void* stream) {
   if (dtype == HECKA_DT_F32)
-    return hecka_gram_bwd_f32(W, static_cast<const float*>(X), wmax, xmax, M, B, P, static_cast<float*>(dX), stream);
+    return hecka_gram_bwd_f32(W, static_cast<const float*>(X), wmax, xmax, gate, M, B, P, static_cast<float*>(dX), stream);
   clear_error();
   if (dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) return fail(HECKA_EINVAL, "gram_bwd_x16: unknown dtype%s");
   if (!W || !X || !dX || !wmax || !xmax) return fail(HECKA_EINVAL, "gram_bwd_x16: null pointer (wmax and xmax are required)%s");
@@ -3244,7 +3268,7 @@ int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wm
   const bool nofold = B <= 1024 && !getenv("HECKA_BWD_FOLD");
 #define HECKA_BWD16(FOLD, E) \
   hipLaunchKernelGGL((gram_bwd_x6_kernel<1, FOLD, E>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P, \
-                     tilesM, tilesN, xcd)
+                     tilesM, tilesN, xcd, gate)
   if (dtype == HECKA_DT_BF16) {
     if (nofold) HECKA_BWD16(false, kElemBF16); else HECKA_BWD16(true, kElemBF16);
   } else {

@@ -41,7 +41,7 @@ SIGNATURES = {
     'hecka_colmean_x16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hecka_gram_center_multi_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
-    'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'hecka_head_fwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_head_bwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_coef_gamma_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     'hecka_combine_slice_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'hecka_batchnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
-    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 

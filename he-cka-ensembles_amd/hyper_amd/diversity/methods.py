@@ -8,6 +8,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..util.collections import flatten_keys
 from .losses import build_loss
 from .model_kernels import FunctionKernel, WeightKernel, build_model_kernel
@@ -173,6 +174,21 @@ class FunctionSVGD(ParticleMethods):
         return loss, {}
 
 
+class _MaskNaN(torch.autograd.Function):
+    """NaN -> 0 in the value; the upstream gradient of a NaN entry is dropped (exact zero), not multiplied."""
+
+    @staticmethod
+    def forward(ctx, rep):
+        nan = torch.isnan(rep)
+        ctx.save_for_backward(nan)
+        return torch.where(nan, torch.zeros_like(rep), rep)
+
+    @staticmethod
+    def backward(ctx, g):
+        (nan,) = ctx.saved_tensors
+        return torch.where(nan, torch.zeros_like(g), g)
+
+
 @register_method('repulsive_kernel')
 class RepulsiveKernel(ParticleMethods):
     """loss = |beta_ind| CE + c_warm |gamma| rep (+ c_warm |gamma_ood| rep_ood); a NaN repulsive term counts as 0."""
@@ -197,15 +213,35 @@ class RepulsiveKernel(ParticleMethods):
         if trainer.training and self.warmup is not None and step is not None and step < self.warmup:
             warm = (1e-8 + step) / self.warmup
         track['ind_kernel'] = OrderedDict()
-        rep = self.model_kernel(flat_params, track['feats_ind'], track['pred_ind'], track['ind_kernel'])
+        rep, masked = self._gated_kernel(self.model_kernel, flat_params, track['feats_ind'], track['pred_ind'], track['ind_kernel'])
         track['ind_rep_loss'] = rep
-        track['loss'] = track['loss'] + warm * torch.abs(self.gamma) * torch.nan_to_num(rep, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+        track['loss'] = track['loss'] + warm * torch.abs(self.gamma) * masked
         if self.use_ood and self.model_kernel_ood is not None:
             track['ood_kernel'] = OrderedDict()
-            rep_ood = self.model_kernel_ood(flat_params, track['feats_ood'], track['pred_ood'], track['ood_kernel'])
+            rep_ood, masked = self._gated_kernel(self.model_kernel_ood, flat_params, track['feats_ood'], track['pred_ood'], track['ood_kernel'])
             track['ood_rep_loss'] = rep_ood
-            track['loss'] = track['loss'] + warm * torch.abs(self.gamma_ood) * torch.nan_to_num(rep_ood, nan=0.0, posinf=float('inf'), neginf=float('-inf'))
+            track['loss'] = track['loss'] + warm * torch.abs(self.gamma_ood) * masked
         return track
+
+    @staticmethod
+    def _gated_kernel(kernel, flat_params, feats, pred, ktrack):
+        """(rep, rep with NaN counted as 0).  The reference reads `rep.isnan()` on the host and drops a NaN term from the
+        loss AND from the graph (methods.py:342-348), so only the data term's gradients flow.  Here nothing is read
+        back: the kernel runs inside ops.grad_gate, its autograd nodes keep the one-element gate, and the gate is set
+        to 0 on the device when the term is NaN - every dX launch of the term then writes exact zeros (a zero upstream
+        alone would give 0 * NaN = NaN in the feature gradients)."""
+        feat0 = next(iter(feats.values()), None) if feats is not None and len(feats) else None
+        if feat0 is None or not feat0.is_cuda:
+            rep = kernel(flat_params, feats, pred, ktrack)
+            return rep, (torch.nan_to_num(rep, nan=0.0, posinf=float('inf'), neginf=float('-inf')) if rep is not None else 0.0)
+        gate = torch.ones((1,), device=feat0.device, dtype=torch.float32)
+        with ops.grad_gate(gate):
+            rep = kernel(flat_params, feats, pred, ktrack)
+        if rep is None:
+            return rep, 0.0
+        with torch.no_grad():
+            gate.copy_((~torch.isnan(rep.detach()).any()).to(torch.float32).reshape(1))
+        return rep, _MaskNaN.apply(rep)
 
     @staticmethod
     def from_config(config):

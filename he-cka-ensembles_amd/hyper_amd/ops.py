@@ -2,7 +2,9 @@
 
 PyTorch is plumbing here: it owns the device memory and the stream; all arithmetic on [M,B,P]
 and [M,B,B] tensors happens in the HIP kernels."""
+import contextlib
 import os
+import threading
 
 import torch
 
@@ -12,6 +14,44 @@ from . import _lib
 # bench.py sets this to {'gram_bwd': []} to collect (start_event, end_event, flops) around the dominant
 # kernel's launches on the launch stream; None in normal operation.
 PROFILE = None
+LAST_BWD_KERNEL = None     # name of the kernel the last dX launch took (bench.py's `roofline.kernel`)
+EXCHANGED_BYTES = 0        # bytes this rank handed to collectives (hyper_amd/parallel.py adds to it; bench.py reports it)
+
+
+def set_gemm_mode(mode):
+    """Arithmetic of the two large GEMMs (include/hecka.h HECKA_GEMM_*): 0 auto (f16x3), 1 fp32 MFMA, 2 bf16x6."""
+    _lib.check(_lib.lib().hecka_set_gemm_mode(int(mode)), 'set_gemm_mode')
+
+
+def get_gemm_mode():
+    return int(_lib.lib().hecka_get_gemm_mode())
+
+
+# ---- gradient gate ------------------------------------------------------------------------------------------------
+# RepulsiveKernel drops a NaN repulsion term from the loss and from the graph (hyper/diversity/methods.py:342-348, a
+# host-side `if rep.isnan()`).  Without a host read-back the same has to happen on the device: the method allocates a
+# one-element gate tensor, runs the model kernel inside `grad_gate(gate)`, and writes 0 into it when the term came out
+# NaN.  Every autograd node built inside the context remembers the gate and hands it to its dX launch
+# (hecka_gram_bwd_*), which then writes exact zeros instead of multiplying NaN Grams by a zero upstream.
+_gate_tls = threading.local()
+
+
+@contextlib.contextmanager
+def grad_gate(gate):
+    prev = getattr(_gate_tls, 'gate', None)
+    _gate_tls.gate = gate
+    try:
+        yield gate
+    finally:
+        _gate_tls.gate = prev
+
+
+def current_gate():
+    return getattr(_gate_tls, 'gate', None)
+
+
+def _gp(gate):
+    return gate.data_ptr() if gate is not None else None
 
 
 def _p(t):
@@ -80,7 +120,10 @@ class _GemmChain:
 
     @classmethod
     def enter(cls, device):
-        if not cls.enabled:
+        if not cls.enabled or torch.cuda.is_current_stream_capturing():
+            # (under graph capture the chain is skipped: an eager event must not be waited on inside a capture, and an
+            # event recorded inside one must not leak into eager code; capture orders the launches by itself)
+            cls.last.pop(device.index, None)
             return None
         cur = torch.cuda.current_stream(device)
         prev = cls.last.get(device.index)
@@ -190,7 +233,7 @@ def pairwise_inner(Ca, Cb=None, out=None):
     return S
 
 
-def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None):
+def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None, gate=None):
     """dX_i = (dC_i + dC_i^T, diag masked) X_i with dC_i = sum_j A[i,j] C[j].
     xmax: [Ma] max |X_i| from centered_gram(return_xmax=True), or None.
     nsq: [Mb] squared Frobenius norms of C (diag of the pairwise matrix), or None: with it the bound on |W| for the
@@ -208,7 +251,7 @@ def gram_backward(A, C, cvec, X, detach_diag, xmax=None, nsq=None):
         _lib.check(L.hecka_wbound_f32(_p(A), _p(nsq), _p(gamma), Ma, Mb, B, _p(wmax), st), 'wbound')
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(gamma), Ma, Mb, B, int(bool(detach_diag)), _p(W),
                                    _p(wmax) if wmax is not None and not bound else None, st), 'combine')
-    return gram_bwd_w(W, X, wmax, xmax)
+    return gram_bwd_w(W, X, wmax, xmax, gate)
 
 
 # --- the stages of gram_backward one by one, for the member-sharded path (hyper_amd/parallel.py), which runs the
@@ -246,21 +289,21 @@ def wbound(A, nsq, gamma):
     return out
 
 
-def gram_bwd_w(W, X, wmax=None, xmax=None):
-    """dX [Ma,B,P] = W [Ma,B,B] X."""
+def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
+    """dX [Ma,B,P] = W [Ma,B,B] X   (gate: one-element fp32 device tensor, 0 = write zeros; see grad_gate)."""
     Ma, B, P = X.shape
     dX = torch.empty_like(X)
-    gate = _GemmChain.enter(X.device)
+    chain = _GemmChain.enter(X.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.lib().hecka_gram_bwd_x16(_p(W), _p(X), _DTYPE_CODE[X.dtype], _p(wmax) if wmax is not None else None,
-                                             _p(xmax) if xmax is not None else None, Ma, B, P, _p(dX), _stream()),
-               'gram_bwd')
+                                             _p(xmax) if xmax is not None else None, _gp(gate), Ma, B, P, _p(dX),
+                                             _stream()), 'gram_bwd')
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
-    _GemmChain.leave(X.device, gate)
+    _GemmChain.leave(X.device, chain)
     return dX
 
 
@@ -371,10 +414,12 @@ class DiversityLayers(torch.autograd.Function):
             ctx.save_for_backward(*Xs, *Cs, *[a[0] for a in aux], *[a[1] for a in aux], *[a[2] for a in aux], S_all, nsq_all)
             ctx.cfg = (specs, scales, bool(detach_diag), Ln)
             ctx.gspecs = list(gspecs)
+            ctx.gate = current_gate()
             ctx.mark_non_differentiable(S_all, nsq_all, *Cs)
             ctx.set_materialize_grads(False)
             return (totals.sum(), S_all, nsq_all) + tuple(Cs)
         ctx.gspecs = None
+        ctx.gate = current_gate()
         if pre is None:
             pre = centered_gram_multi(Xs)
         Cs = [p[0] for p in pre]
@@ -403,7 +448,7 @@ class DiversityLayers(torch.autograd.Function):
                 return (None,) + tuple(torch.zeros_like(X) for X in Xs)
             A_all = head_backward_batched(S_all, nsq_all, 0, specs, dout.contiguous().float(), scales)
             return (None,) + tuple(transformed_gram_backward(A_all[li], Cs[li], rmeans[li], gdiags[li], hbands[li], Xs[li],
-                                                             ctx.gspecs[li]) for li in range(Ln))
+                                                             ctx.gspecs[li], ctx.gate) for li in range(Ln))
         Xs, Cs, xmaxs = t[:Ln], t[Ln:2 * Ln], t[2 * Ln:3 * Ln]
         cv_all, S_all, nsq_all = t[3 * Ln:]
         if dout is None:
@@ -415,7 +460,7 @@ class DiversityLayers(torch.autograd.Function):
         grads = []
         for li in range(Ln):
             W = combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag)
-            grads.append(gram_bwd_w(W, Xs[li], wmax_all[li], xmaxs[li]))
+            grads.append(gram_bwd_w(W, Xs[li], wmax_all[li], xmaxs[li], ctx.gate))
         return (None,) + tuple(grads)
 
 
@@ -445,6 +490,7 @@ class CenteredGramPairwise(torch.autograd.Function):
         nsq = torch.diagonal(S).clone()
         ctx.save_for_backward(X, C, cvec, xmax)
         ctx.detach_diag, ctx.left_only = bool(detach_diag), bool(left_only)
+        ctx.gate = current_gate()
         ctx.mark_non_differentiable(C)
         ctx.set_materialize_grads(False)
         return S, nsq, C
@@ -458,7 +504,7 @@ class CenteredGramPairwise(torch.autograd.Function):
             A = A + (dS if ctx.left_only else dS + dS.t())
         if dnsq is not None:
             A = A + torch.diag_embed(2.0 * dnsq)
-        dX = gram_backward(A.contiguous(), C, cvec, X, ctx.detach_diag, xmax)
+        dX = gram_backward(A.contiguous(), C, cvec, X, ctx.detach_diag, xmax, gate=ctx.gate)
         return dX, None, None
 
 
@@ -515,6 +561,7 @@ class LinearGram(torch.autograd.Function):
         _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(K), _p(cvec), _stream()), 'gram')
         ctx.save_for_backward(X)
         ctx.detach_diag = bool(detach_diag)
+        ctx.gate = current_gate()
         return K
 
     @staticmethod
@@ -527,7 +574,7 @@ class LinearGram(torch.autograd.Function):
         dX = torch.empty_like(X)
         st = _stream()
         _lib.check(L.hecka_symmetrize_f32(_p(dK), M, B, int(ctx.detach_diag), _p(W), st), 'symmetrize')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), st), 'gram_bwd')
         return dX, None
 
 
@@ -621,7 +668,7 @@ def transformed_gram(X, gspec, center, out=None):
     return C, rmean, gdiag, hband
 
 
-def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec):
+def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec, gate=None):
     """dX for a cossim / rbf layer from the coefficient matrix A (dC_i = sum_j A_ij C_j)."""
     L = _lib.lib()
     M, B, P = X.shape
@@ -633,7 +680,7 @@ def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec):
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), None, st), 'combine')
     _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(C), _p(rmean), _p(gdiag), _p(hband), M, B, gspec.kind, st),
                'gram_transform_bwd')
-    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(gate), M, B, P, _p(dX), st), 'gram_bwd')
     return dX
 
 
@@ -671,6 +718,7 @@ class DiversityLayer(torch.autograd.Function):
             _lib.check(L.hecka_head_fwd_f32(_p(S), _p(nsq), M, M, 0, *spec.args(), None, _p(out), ctx.scale, st), 'head_fwd')
         ctx.save_for_backward(X, C, S, nsq, *aux)
         ctx.spec, ctx.detach_diag, ctx.reduced, ctx.gspec = spec, bool(detach_diag), reduce is not None, gspec
+        ctx.gate = current_gate()
         ctx.mark_non_differentiable(C, S, nsq)
         ctx.set_materialize_grads(False)   # no zeros_like(C) for the non-differentiable by-products
         return out, C, S, nsq              # S [M,M] / nsq [M]: inner products and squared norms of the Grams (metrics)
@@ -689,9 +737,9 @@ class DiversityLayer(torch.autograd.Function):
         _lib.check(L.hecka_head_bwd_f32(_p(S), _p(nsq), M, M, 0, *ctx.spec.args(), up_mat, up_scalar, ctx.scale, _p(A),
                                         _stream()), 'head_bwd')
         if len(aux) == 2:
-            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag, aux[1], nsq)
+            dX = gram_backward(A, C, aux[0], X, ctx.detach_diag, aux[1], nsq, gate=ctx.gate)
         else:
-            dX = transformed_gram_backward(A, C, aux[0], aux[1], aux[2], X, ctx.gspec)
+            dX = transformed_gram_backward(A, C, aux[0], aux[1], aux[2], X, ctx.gspec, ctx.gate)
         return dX, None, None, None, None, None
 
 
@@ -745,6 +793,7 @@ class TransformedGram(torch.autograd.Function):
         K, rmean, gdiag, hband = transformed_gram(X, gspec, False)
         ctx.save_for_backward(X, K, gdiag, hband)
         ctx.gspec, ctx.left_only = gspec, bool(left_only)
+        ctx.gate = current_gate()
         return K
 
     @staticmethod
@@ -764,7 +813,7 @@ class TransformedGram(torch.autograd.Function):
             _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
         _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(K), None, _p(gdiag), _p(hband), M, B, ctx.gspec.kind, st),
                    'gram_transform_bwd')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), st), 'gram_bwd')
         return dX, None, None
 
 

@@ -147,6 +147,7 @@ class _SlicedLayers(torch.autograd.Function):
         ctx.batch = (S_all, nsq_all, cv_all, specs, scales) if batched else None
         ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
         ctx.geom = (world, rank, Ml, B, bounds, ns)
+        ctx.gate = getattr(backend, 'current_gate', lambda: None)()     # ops.grad_gate: a masked NaN term gives dX = 0
         return total.clone()
 
     @staticmethod
@@ -189,7 +190,8 @@ class _SlicedLayers(torch.autograd.Function):
                 for g in range(world):
                     W[:, bounds[g]:bounds[g + 1]] = recv[off:off + Ml * ns[g]].view(Ml, ns[g])
                     off += Ml * ns[g]
-            grads.append(be.gram_bwd_w(W.view(Ml, B, B), X, wmax, xmax))
+            gate = (ctx.gate,) if ctx.gate is not None else ()
+            grads.append(be.gram_bwd_w(W.view(Ml, B, B), X, wmax, xmax, *gate))
         return (None,) + tuple(grads)
 
 
@@ -229,6 +231,7 @@ class _GatheredLayers(torch.autograd.Function):
         total = total.clone()
         _all_reduce(total, group)
         ctx.saved, ctx.backend, ctx.r0, ctx.detach = saved, backend, r0, detach
+        ctx.gate = getattr(backend, 'current_gate', lambda: None)()
         return total
 
     @staticmethod
@@ -237,7 +240,8 @@ class _GatheredLayers(torch.autograd.Function):
         grads = []
         for X, C_all, cv_all, S, nsq, spec, scale, xmax in ctx.saved:
             A = ctx.backend.head_backward(S, nsq, ctx.r0, spec, dloss, scale)
-            grads.append(ctx.backend.gram_backward(A, C_all, cv_all, X, ctx.detach, xmax))
+            gate = {'gate': ctx.gate} if ctx.gate is not None else {}
+            grads.append(ctx.backend.gram_backward(A, C_all, cv_all, X, ctx.detach, xmax, **gate))
         return (None,) + tuple(grads)
 
 

@@ -329,14 +329,17 @@ size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
                                 float* const* cvec, void* ws, size_t ws_bytes, void* stream);
-int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, int M, int B,
-                       int P, void* dX, void* stream);
+int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate,
+                       int M, int B, int P, void* dX, void* stream);
 
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
- * hecka_colmean_f32, or upper bounds of them (hecka_wbound_f32); both given enables f16x3 (see HECKA_GEMM_AUTO). */
-int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, int M, int B, int P,
-                       float* dX, void* stream);
+ * hecka_colmean_f32, or upper bounds of them (hecka_wbound_f32); both given enables f16x3 (see HECKA_GEMM_AUTO).
+ * gate (may be NULL): device scalar; when *gate == 0 the call writes dX = 0 and reads neither W nor X.  RepulsiveKernel
+ * drops a NaN repulsion term from the loss AND from the graph (hyper/diversity/methods.py:342-348: `if rep.isnan()` on the
+ * host); here the caller sets *gate = 0 on the device instead, so that no 0 * NaN product reaches the feature gradients. */
+int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, const float* gate, int M, int B,
+                       int P, float* dX, void* stream);
 
 #ifdef __cplusplus
 }

@@ -217,6 +217,40 @@ def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
         assert err <= RTOL, err
 
 
+@pytest.mark.parametrize('style', ['randn', 'correlated'])
+def test_bench_workload_five_layers_against_fp64_oracle(style):
+    """The EXACT bench.py workload (BASELINE configs[3]): all five layers P = 512 .. 8192 at M = 64, B = 512 through the
+    fused `model_layers` node (one Gram launch for all layers, batched heads, K = 8192 accumulation chains of the f16x3
+    split) against the oracle in fp64 on the same tensors (evaluated with stock torch ops on the GPU; X at P = 8192 is
+    2 GB in fp64).  Power head (configs/mnist/ens/he-lin.yml) and use_exp head (configs/cifar10/ens/he-lin.yml); the
+    default f16x3 arithmetic and HECKA_GEMM_BF16X6.  rel 1e-5 on the loss and on every layer's gradient (max-norm)."""
+    import bench
+    from hyper_amd import ops
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from collections import OrderedDict
+    dev = _dev()
+    feats = bench.make_feats(dev, slice(0, bench.M), correlated=(style == 'correlated'))
+    assert [tuple(f.shape) for f in feats] == [(64, 512, p) for p in (512, 1024, 2048, 4096, 8192)]
+    for cfg in (bench.CFG, bench.CFG_EXP):
+        ref_loss, ref_grads = bench.oracle_fp64_on_gpu(cfg, feats)
+        try:
+            for mode in (0, 2):
+                ops.set_gemm_mode(mode)
+                xs = [f.detach().clone().requires_grad_(True) for f in feats]
+                track = OrderedDict()
+                out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
+                out.backward()
+                assert len(track['layer_track']) == 5
+                rec = bench.parity_record(float(out.item()), [x.grad for x in xs], ref_loss, ref_grads)
+                assert rec['loss_rel'] <= RTOL, (mode, rec)
+                assert rec['grad_rel_max'] <= RTOL, (mode, rec)
+                del xs, out, track
+        finally:
+            ops.set_gemm_mode(0)
+        del ref_grads
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('dtype,native', [('bfloat16', '1'), ('float16', '1'), ('bfloat16', '0'), ('bfloat16', 'exact')])
 @pytest.mark.parametrize('dims', [(256, 1024), (128,), (256, 80)])
 def test_16bit_features_match_oracle_on_rounded_values(dtype, native, dims, monkeypatch):
@@ -680,6 +714,52 @@ def test_cossim_zero_row_is_nan_and_the_method_masks_it():
     track = method(types.SimpleNamespace(training=True), OrderedDict(), [], track, None, torch.randint(0, 3, (6,), device=dev), step=5)
     assert torch.isnan(track['ind_rep_loss']) and torch.isfinite(track['loss'])
     assert abs(track['loss'].item() - track['ind_loss'].item()) < 1e-6
+
+
+@pytest.mark.parametrize('kernel,learnable', [('cossim', False), ('linear', False), ('cossim', True)])
+def test_masked_nan_term_leaves_only_the_data_gradients(kernel, learnable):
+    """The reference drops a NaN repulsion term from the graph (methods.py:342-348): backward then carries the data
+    term's gradients only.  Here the term is masked on the device (ops.grad_gate): the feature gradients of the NaN term
+    must be exact zeros - not 0 * NaN - and the prediction gradients those of the cross-entropy alone.  cossim: a zero
+    feature row; linear: a NaN feature; learnable: the [M,M] head in torch on top of the HIP Gram kernels."""
+    import types
+    from collections import OrderedDict
+    from hyper_amd.diversity.methods import build_method
+    dev = _dev()
+    mk = {'name': 'model_layers', 'layer_weighting': {'name': 'uniform'},
+          'layer_kernel': dict(name='he', eps=0.0025, arc_eps=0.031, learnable=learnable,
+                               feature_kernel={'name': 'feature', 'detach_diag': True, 'kernel': kernel})}
+    torch.manual_seed(3)
+    x0 = torch.randn(4, 6, 5)
+    x0[1, 2] = 0.0 if kernel == 'cossim' else float('nan')
+    x1 = torch.randn(4, 6, 7)
+    method = build_method({'name': 'repulsive_kernel', 'num': 4, 'gamma': 2.0, 'model_kernel': mk,
+                           'ind_loss': {'name': 'cross_entropy'}}).to(dev)
+    gt = torch.randint(0, 3, (6,), device=dev)
+    pred0 = torch.randn(4, 6, 3, device=dev)
+
+    def run(feats_a, feats_b):
+        pred = pred0.clone().requires_grad_(True)
+        xa, xb = feats_a.to(dev).requires_grad_(True), feats_b.to(dev).requires_grad_(True)
+        # the features depend on the predictions' leaf too, as in a network (shared upstream graph)
+        track = {'pred_ind': pred, 'feats_ind': OrderedDict(a=xa * 1.0, b=xb * 1.0), 'pred_ood': None, 'feats_ood': None}
+        track = method(types.SimpleNamespace(training=True), OrderedDict(), [], track, None, gt, step=5)
+        track['loss'].backward()
+        return track, pred.grad, xa.grad, xb.grad
+
+    track, gp, ga, gb = run(x0, x1)
+    assert torch.isnan(track['ind_rep_loss']) and torch.isfinite(track['loss'])
+    assert torch.equal(ga, torch.zeros_like(ga)) and torch.equal(gb, torch.zeros_like(gb))
+    # the data term alone
+    pred = pred0.clone().requires_grad_(True)
+    ce = build_method({'name': 'mle', 'num': 4, 'ind_loss': {'name': 'cross_entropy'}}).to(dev)
+    t2 = ce(types.SimpleNamespace(training=True), OrderedDict(), [], {'pred_ind': pred, 'feats_ind': OrderedDict(), 'pred_ood': None,
+                                                                     'feats_ood': None}, None, gt, step=5)
+    t2['loss'].backward()
+    assert torch.isfinite(gp).all() and torch.allclose(gp, pred.grad, rtol=1e-6, atol=1e-8)
+    # a finite term right afterwards: the gate is per call, gradients flow again
+    track, gp, ga, gb = run(torch.randn(4, 6, 5), x1)
+    assert torch.isfinite(track['ind_rep_loss']) and float(ga.abs().max()) > 0 and float(gb.abs().max()) > 0
 
 
 def test_graphed_train_step_equals_eager():

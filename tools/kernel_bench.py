@@ -41,7 +41,7 @@ fns = {
     'combine': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st), 2.0 * M * M * B * B, 8.0 * M * B * B),
     'combine_nomax': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), None, st), 2.0 * M * M * B * B, 8.0 * M * B * B),
     'head_fwd': (lambda: L.hecka_head_fwd_f32(p(S), p(nsq), M, M, 0, 1, 2.0, 0.0025, 0.031, 4, None, p(tot), 1.0, st), 0, 0),
-    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), p(wmax), p(xmax), M, B, P, p(dX), st), 2.0 * M * B * B * P, 0),
+    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), p(wmax), p(xmax), None, M, B, P, p(dX), st), 2.0 * M * B * B * P, 0),
 }
 L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st)   # W and wmax consistent for gram_bwd
 L.hecka_pairwise_f32(p(C), M, p(C), M, B * B, p(S), p(ws), nb, st)

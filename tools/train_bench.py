@@ -82,26 +82,16 @@ def _with_cifar_hyper(cfgs):
     return cfgs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('config', choices=['mnist', 'toy', 'cifar', 'hyper', 'hyper_cifar'])
-    ap.add_argument('--impl', default='amd', choices=['amd', 'ref'])
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--members', type=int, default=0)
-    ap.add_argument('--batch', type=int, default=0)
-    ap.add_argument('--no-fused', action='store_true', help='torch default (foreach) AdamW instead of the fused kernel')
-    ap.add_argument('--bf16-features', action='store_true', help='tracked features enter the loss as bf16 (BASELINE configs[2])')
-    ap.add_argument('--graph', action='store_true', help='capture the step in one HIP graph (hyper_amd.experiments.graphed)')
-    args = ap.parse_args()
-    c = _with_cifar_hyper(configs(args.members))[args.config]
-    M, B = c['members'], args.batch or c['batch']
+def run(config, impl='amd', steps=20, warmup=3, members=0, batch=0, no_fused=False, bf16_features=False, graph=False):
+    """A few training steps of one configuration; returns {'ms_per_step', 'steps_per_s', 'loss', 'members', 'batch'}."""
+    c = _with_cifar_hyper(configs(members))[config]
+    M, B = c['members'], batch or c['batch']
     if not c.get('sampled'):
         c['hyper']['ensemble_size'] = M
     ood = c.get('ood', 0)
     ids = M if c.get('sampled') else list(range(M))
     c['method']['num'] = M
-    if args.impl == 'ref':
+    if impl == 'ref':
         sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
         import make_golden
         make_golden._import_reference()
@@ -121,9 +111,9 @@ def main():
     params = list(hyper.parameters()) + list(method.parameters())
     # fused=True: one multi-tensor kernel per step instead of ~ten foreach passes over every parameter (70 M of them in
     # the hypernetwork); the reference's trainer takes torch's default (foreach)
-    opt = (torch.optim.AdamW(params, lr=1e-3, capturable=args.graph, fused=(args.impl == 'amd' and not args.no_fused))
+    opt = (torch.optim.AdamW(params, lr=1e-3, capturable=graph, fused=(impl == 'amd' and not no_fused))
            if c['opt'] == 'adamw'
-           else torch.optim.SGD(params, lr=0.01, momentum=0.9, fused=(args.impl == 'amd' and not args.no_fused)))
+           else torch.optim.SGD(params, lr=0.01, momentum=0.9, fused=(impl == 'amd' and not no_fused)))
     X = torch.randn(B + ood, *c['x'], device=dev)
     Y = torch.randint(0, c['classes'], (B,), device=dev)
     trainer = types.SimpleNamespace(training=True)
@@ -131,7 +121,7 @@ def main():
     def step(i):
         opt.zero_grad(set_to_none=True)
         track = hyper(params=ids, x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=ood)
-        if args.bf16_features:
+        if bf16_features:
             for key in ('feats_ind', 'feats_ood'):
                 if track.get(key) is not None:
                     track[key] = type(track[key])((k, v.bfloat16()) for k, v in track[key].items())
@@ -145,22 +135,39 @@ def main():
         opt.step()
         return track['loss']
 
-    if args.graph:
+    if graph:
         from hyper_amd.experiments.graphed import GraphedTrainStep
         graphed = GraphedTrainStep(hyper, method, opt, X, Y, member_ids=ids, step=3000, forward_kwargs={'ood_N': ood})
         step = lambda i: graphed()   # noqa: E731
     sync = torch.cuda.synchronize if dev.type == 'cuda' else (lambda: None)
-    for i in range(args.warmup):
+    for i in range(warmup):
         loss = step(i)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step(i)
     sync()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
+    return {'ms_per_step': dt * 1e3, 'steps_per_s': 1.0 / dt, 'loss': float(loss), 'members': M, 'batch': B}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config', choices=['mnist', 'toy', 'cifar', 'hyper', 'hyper_cifar'])
+    ap.add_argument('--impl', default='amd', choices=['amd', 'ref'])
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--members', type=int, default=0)
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--no-fused', action='store_true', help='torch default (foreach) AdamW instead of the fused kernel')
+    ap.add_argument('--bf16-features', action='store_true', help='tracked features enter the loss as bf16 (BASELINE configs[2])')
+    ap.add_argument('--graph', action='store_true', help='capture the step in one HIP graph (hyper_amd.experiments.graphed)')
+    args = ap.parse_args()
+    r = run(args.config, args.impl, args.steps, args.warmup, args.members, args.batch, args.no_fused, args.bf16_features,
+            args.graph)
     print('%s impl=%s M=%d B=%d: %.2f ms/step  %.1f steps/s  loss %.4f%s' % (
-        args.config, args.impl + ('+graph' if args.graph else ''), M, B, dt * 1e3, 1.0 / dt, float(loss),
-        '  (%d CPU threads)' % torch.get_num_threads() if args.impl == 'ref' else ''))
+        args.config, args.impl + ('+graph' if args.graph else ''), r['members'], r['batch'], r['ms_per_step'],
+        r['steps_per_s'], r['loss'], '  (%d CPU threads)' % torch.get_num_threads() if args.impl == 'ref' else ''))
 
 
 if __name__ == '__main__':
