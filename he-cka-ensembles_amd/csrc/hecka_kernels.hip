@@ -2224,7 +2224,7 @@ int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar
   if (!X || !sbar || !xmax) return fail(HECKA_EINVAL, "colmean_x16: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "colmean_x16: bad size%s");
   if (P % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 7) || !aligned16(sbar))
-    return fail(HECKA_EINVAL, "colmean_x16: needs P %% 4 == 0 and aligned rows (P = %lld)%s", "", P);
+    return fail(HECKA_EINVAL, "%scolmean_x16: needs P %% 4 == 0 and aligned rows (P = %lld)", "", P);
   dim3 grid((P + 127) / 128, M);
   hipStream_t st = (hipStream_t)stream;
   unsigned* xm = reinterpret_cast<unsigned*>(xmax);
@@ -2345,7 +2345,7 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
   if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
-  if (M <= 0 || B <= 0 || B % 128 != 0) return fail(HECKA_EINVAL, "gram_center_multi: needs B %% 128 == 0 (B = %lld)%s", "", B);
+  if (M <= 0 || B <= 0 || B % 128 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: needs B %% 128 == 0 (B = %lld)", "", B);
   if (g_gemm_mode == HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "gram_center_multi: not available in HECKA_GEMM_FP32 mode%s");
   const int ntile = B / 128, per = M * (ntile * (ntile + 1) / 2);
   bool have_max = xmax != nullptr;
@@ -2354,9 +2354,9 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   a.M = M;
   int nsp[kMaxGramLayers], kch[kMaxGramLayers];
   for (int i = 0; i < L; ++i)
-    if (P[i] <= 0 || P[i] % 16 != 0) return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0 (P = %lld)%s", "", P[i]);
+    if (P[i] <= 0 || P[i] % 16 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs P %% 16 == 0 (P = %lld)", "", P[i]);
   const size_t need = ws ? gram_split_plan(L, M, B, P, nsp, kch) : 0;   // no workspace given: no split
-  if (need > ws_bytes) return fail(HECKA_EWORKSPACE, "gram_center_multi: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  if (need > ws_bytes) return fail(HECKA_EWORKSPACE, "%sgram_center_multi: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   if (!need)
     for (int i = 0; i < L; ++i) { nsp[i] = 1; kch[i] = P[i]; }
   float* wsp = static_cast<float*>(ws);
@@ -2365,7 +2365,7 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   for (int i = 0; i < L; ++i) {
     if (!X[i] || !sbar[i] || !C[i] || !cvec[i]) return fail(HECKA_EINVAL, "gram_center_multi: null layer pointer%s");
     if (P[i] <= 0 || P[i] % 16 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * es >= (1ll << 32))
-      return fail(HECKA_EINVAL, "gram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)%s", "", P[i]);
+      return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)", "", P[i]);
     if (i > 0 && P[i] > P[i - 1]) return fail(HECKA_EINVAL, "gram_center_multi: layers must come deepest (largest P) first%s");
     have_max = have_max && xmax[i] != nullptr;
     wg += (long long)per * nsp[i];
@@ -2418,10 +2418,10 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   clear_error();
   if (!Ca || !Cb || !S || !ws) return fail(HECKA_EINVAL, "pairwise: null pointer%s");
   if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise: non-positive size%s");
-  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "pairwise: K too large (%lld)%s", "", K);
+  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "%spairwise: K too large (%lld)", "", K);
   const int nsplit = pairwise_nsplit(Ma, Mb, K);
   if (ws_bytes < (size_t)nsplit * Ma * Mb * sizeof(float))
-    return fail(HECKA_EWORKSPACE, "pairwise: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+    return fail(HECKA_EWORKSPACE, "%spairwise: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   GemmOperands g;
   g.A = Ca; g.B = Cb;
   g.strideA = g.strideB = 0;
@@ -2458,10 +2458,10 @@ int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long 
   clear_error();
   if (!C_all || !S_all || !ws) return fail(HECKA_EINVAL, "pairwise_self_batched: null pointer%s");
   if (L <= 0 || L > 65535 || M <= 0 || K <= 0 || K > 0x7fffffffLL - 64)
-    return fail(HECKA_EINVAL, "pairwise_self_batched: size out of range (K = %lld)%s", "", K);
+    return fail(HECKA_EINVAL, "%spairwise_self_batched: size out of range (K = %lld)", "", K);
   const int nsplit = pairwise_nsplit(M, M, K);
   if (ws_bytes < (size_t)L * nsplit * M * M * sizeof(float))
-    return fail(HECKA_EWORKSPACE, "pairwise_self_batched: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+    return fail(HECKA_EWORKSPACE, "%spairwise_self_batched: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   hipStream_t st = (hipStream_t)stream;
   if (M != 64 || K % 32 != 0 || 64 * K * 4 >= (1ll << 31) || !aligned16(C_all)) {
     // any member count: the LDS-tiled kernel with the layer in blockIdx.y
@@ -2789,7 +2789,7 @@ int hecka_bgemm_splitk_f32(const float* A, const float* Bm, float* C, int batch,
   if (nsplit < 2) return fail(HECKA_EINVAL, "bgemm_splitk: this shape does not split (workspace query returns 0): use hecka_bgemm_f32%s");
   const long long n = (long long)batch * rows * cols;
   if (ws_bytes < (size_t)nsplit * n * sizeof(float) || n > 0x7fffffffLL)
-    return fail(HECKA_EWORKSPACE, "bgemm_splitk: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+    return fail(HECKA_EWORKSPACE, "%sbgemm_splitk: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   GemmOperands g;
   g.A = A; g.B = Bm;
   g.strideA = strideA; g.strideB = strideB;
@@ -2855,7 +2855,7 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
     return fail(HECKA_EINVAL, "bgemm_x3: needs HECKA_GEMM_AUTO, rows %% 64 == 0, cols %% 128 == 0, K %% 16 == 0, 16-byte alignment%s");
   const int ns = bgemm_x3_nsplit(batch, rows, cols, K);
   const size_t need = ns > 1 ? (size_t)ns * batch * rows * cols * sizeof(float) : 0;
-  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "bgemm_x3: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "%sbgemm_x3: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   const int tm = rows % 128 ? 64 : 128;
   const int tilesM = rows / tm, tilesN = cols / 128;
   const long long ktiles = K / kX6BK;
@@ -2949,7 +2949,7 @@ int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const in
   const long long Q = (long long)N * H * W;
   const int ns = conv_wgrad_nsplit(batch, O, Rp, Q);
   const size_t need = ns > 1 ? (size_t)ns * batch * O * Rp * sizeof(float) : 0;
-  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "conv_wgrad_x3: workspace too small (%lld bytes given)%s", "", (long long)ws_bytes);
+  if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "%sconv_wgrad_x3: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   const int tm = O % 128 ? 64 : 128;
   const int tilesM = O / tm, tilesN = Rp / 128;
   const int kchunk = (int)((((Q / 16) + ns - 1) / ns) * 16);
