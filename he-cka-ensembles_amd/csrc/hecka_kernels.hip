@@ -2413,15 +2413,9 @@ size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {
   return (size_t)pairwise_nsplit(Ma, Mb, K) * Ma * Mb * sizeof(float);
 }
 
-int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* ws,
-                       size_t ws_bytes, void* stream) {
-  clear_error();
-  if (!Ca || !Cb || !S || !ws) return fail(HECKA_EINVAL, "pairwise: null pointer%s");
-  if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise: non-positive size%s");
-  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "%spairwise: K too large (%lld)", "", K);
-  const int nsplit = pairwise_nsplit(Ma, Mb, K);
-  if (ws_bytes < (size_t)nsplit * Ma * Mb * sizeof(float))
-    return fail(HECKA_EWORKSPACE, "%spairwise: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
+// the launches of hecka_pairwise_f32, shared with the allocation-free variant below (part: nsplit slabs of [Ma,Mb])
+static int pairwise_launch(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, float* part, int nsplit,
+                           hipStream_t st) {
   GemmOperands g;
   g.A = Ca; g.B = Cb;
   g.strideA = g.strideB = 0;
@@ -2433,8 +2427,6 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   const bool vec = (K % 4 == 0) && aligned16(Ca) && aligned16(Cb);
   const int tilesM = (Ma + 63) / 64, tilesN = (Mb + 63) / 64;
   dim3 grid(tilesM * tilesN, 1, nsplit);
-  hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)ws;
   const bool full = vec && (Ma % 64 == 0) && (Mb % 64 == 0) && (K % kBK == 0);
   if (Ca == Cb && Ma == 64 && Mb == 64 && K % 32 == 0 && vec && 64 * K * 4 < (1ll << 31) && !getenv("HECKA_PAIRWISE_TILED")) {
     const long long nsteps = K / 32;
@@ -2451,6 +2443,53 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
   const int n = Ma * Mb;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, part, nsplit, n, S, 1.0f);
   return check_launch("pairwise_reduce");
+}
+
+int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* ws,
+                       size_t ws_bytes, void* stream) {
+  clear_error();
+  if (!Ca || !Cb || !S || !ws) return fail(HECKA_EINVAL, "pairwise: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise: non-positive size%s");
+  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "%spairwise: K too large (%lld)", "", K);
+  const int nsplit = pairwise_nsplit(Ma, Mb, K);
+  if (ws_bytes < (size_t)nsplit * Ma * Mb * sizeof(float))
+    return fail(HECKA_EWORKSPACE, "%spairwise: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
+  return pairwise_launch(Ca, Ma, Cb, Mb, K, S, (float*)ws, nsplit, (hipStream_t)stream);
+}
+
+// ---- hecka_pairwise_noalloc_f32: hecka_pairwise_f32 for callers that cannot allocate --------------------------------
+// The split-K partial slabs live in a file-scope device array instead of a caller workspace.  `g_pairwise_scratch` is a
+// HOST-side stand-in for the symbol: its device address differs per GPU and is looked up once per device with
+// hipGetSymbolAddress (first call on that device, with the device current); only that pointer is ever handed to a kernel.
+constexpr size_t kNoallocScratchFloats = (size_t)2 << 20;   // 8 MiB per GPU, held until the process ends
+static __device__ __align__(256) float g_pairwise_scratch[kNoallocScratchFloats];
+constexpr int kMaxDevices = 64;
+static float* g_pairwise_scratch_ptr[kMaxDevices] = {};
+
+int hecka_pairwise_noalloc_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* stream) {
+  clear_error();
+  if (!Ca || !Cb || !S) return fail(HECKA_EINVAL, "pairwise_noalloc: null pointer%s");
+  if (Ma <= 0 || Mb <= 0 || K <= 0) return fail(HECKA_EINVAL, "pairwise_noalloc: non-positive size%s");
+  if (K > 0x7fffffffLL - 64) return fail(HECKA_EINVAL, "%spairwise_noalloc: K too large (%lld)", "", K);
+  const int nsplit = pairwise_nsplit(Ma, Mb, K);
+  const size_t need = (size_t)nsplit * Ma * Mb;
+  if (need > kNoallocScratchFloats)
+    return fail(HECKA_EWORKSPACE, "pairwise_noalloc: %s%lld bytes of partial sums exceed the 8 MiB built-in scratch; use hecka_pairwise_f32",
+                "", (long long)(need * sizeof(float)));
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return fail(HECKA_ELAUNCH, "%spairwise_noalloc: no current device (%lld)", "", dev);
+  float* part = __atomic_load_n(&g_pairwise_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!part) {     // set-up, once per device (two threads racing here look up the same address)
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_pairwise_scratch));
+    if (e != hipSuccess || !p) return fail(HECKA_ELAUNCH, "%spairwise_noalloc: hipGetSymbolAddress failed (%lld)", "", (long long)e);
+    part = static_cast<float*>(p);
+    __atomic_store_n(&g_pairwise_scratch_ptr[dev], part, __ATOMIC_RELEASE);
+  }
+  // every slab element is written by the first stage before the second stage reads it: nothing has to start at zero,
+  // whatever the previous call left in the array
+  return pairwise_launch(Ca, Ma, Cb, Mb, K, S, part, nsplit, (hipStream_t)stream);
 }
 
 int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long K, float* S_all, void* ws, size_t ws_bytes,
