@@ -296,7 +296,7 @@ struct GemmTileX6 {
     // or the loads of one operand: about one 32-cycle MFMA).  FIRST: the local chain starts from zero.  GUARD: tail tiles, where
     // tile kt+1 / kt+3 may not exist; the steady-state instance has no branch inside.
     static_assert(SCHEME == 1 || (TM == 128 && TN == 128), "the bf16x6 schedule is written for the 128x128 tile");
-    static_assert((TM == 128 || TM == 64) && TN == 128, "tile: 128 or 64 rows by 128 columns");
+    static_assert((TM == 256 || TM == 128 || TM == 64) && TN == 128, "tile: 256, 128 or 64 rows by 128 columns");
     auto iter = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(NSET)::value;
       constexpr bool G = decltype(GUARD)::value;

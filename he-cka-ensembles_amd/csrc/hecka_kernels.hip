@@ -949,21 +949,25 @@ struct ScaleProX6 {
 
 // EX: element kind of X and dX.  16-bit features times the power-of-two scale are exact in one fp16 term, so X has no
 // low plane (two products per multiply instead of three) and dX is rounded once, to the feature type, on the way out.
-template <int SCHEME, bool FOLD = true, int EX = kElemF32>
-__global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
+// TM = 256 (no local chains only): each wave owns 128 x 64 of a 256 x 128 tile - a staged X tile feeds twice the MFMAs
+// (24 per k-tile per wave behind one barrier), fragment reads and staging work per MFMA fall by a quarter; two
+// workgroups per CU (128 accumulator registers per lane).
+template <int SCHEME, bool FOLD = true, int EX = kElemF32, int TM = 128>
+__global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
                                                                   const unsigned* __restrict__ wmax,
                                                                   const float* __restrict__ xmax,
                                                                   void* __restrict__ dX, int B, int P, int tilesM,
                                                                   int tilesN, int xcd_map, const float* __restrict__ gate) {
-  using Tile = GemmTileX6<128, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32>;
+  static_assert(TM == 128 || !FOLD, "the 256-row tile has no registers for local chains");
+  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
   member_tile(tilesM * tilesN, xcd_map, m, tl);
   const int ti = tl % tilesM, tj = tl / tilesM;
   if (gate && *gate == 0.f) {
-    if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * 128, tj * 128, B, P, 128, 128);
-    else zero_tile(static_cast<unsigned short*>(dX) + (size_t)m * B * P, (size_t)P, ti * 128, tj * 128, B, P, 128, 128);
+    if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * 128, B, P, TM, 128);
+    else zero_tile(static_cast<unsigned short*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * 128, B, P, TM, 128);
     return;
   }
   ScaleProX6<SCHEME> pro;
@@ -972,9 +976,9 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void gram_bwd_x6_kernel(con
   const float unscale = SCHEME == 1 ? 1.0f / (pro.sa * pro.sb) : 1.0f;
   Tile tile;
   tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
-           (unsigned)B * P * ES, P, ti * 128, tj * 128, 0, B, pro);
+           (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro);
   tile.for_each([&](int lr, int lc, float v) {
-    const size_t idx = (size_t)m * B * P + (size_t)(ti * 128 + lr) * P + tj * 128 + lc;
+    const size_t idx = (size_t)m * B * P + (size_t)(ti * TM + lr) * P + tj * 128 + lc;
     const float r = SCHEME == 1 ? v * unscale : v;
     if (EX == kElemF32) static_cast<float*>(dX)[idx] = r;
     else if (EX == kElemBF16) static_cast<__bf16*>(dX)[idx] = (__bf16)r;
@@ -3262,7 +3266,12 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
   // K = B <= 1024: one accumulation chain (no local 64-k chains): 153 instead of 230 VGPRs, three workgroups per CU,
   // +6 % - the end-to-end gradient error stays 0.7 - 2.5e-6 of max |dX| (with local chains 0.4 - 2.4e-6;
   // tools/grad_margin.py, tools/bwd_accuracy.py).  HECKA_BWD_FOLD=1 keeps the local chains.
-  if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO && B <= 1024 && !getenv("HECKA_BWD_FOLD"))
+  static const int bwd_tile = getenv("HECKA_BWD_TILE") ? atoi(getenv("HECKA_BWD_TILE")) : 256;
+  if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO && B <= 1024 && B % 256 == 0 && bwd_tile == 256 &&
+      !getenv("HECKA_BWD_FOLD"))
+    hipLaunchKernelGGL((gram_bwd_x6_kernel<1, false, kElemF32, 256>), dim3((unsigned)(nwg / 2)), dim3(kThreads), 0, st, W, X, wm,
+                       xmax, dX, B, P, tilesM / 2, tilesN, (int)(M % 8 == 0), gate);
+  else if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO && B <= 1024 && !getenv("HECKA_BWD_FOLD"))
     hipLaunchKernelGGL((gram_bwd_x6_kernel<1, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm, xmax, dX, B, P,
                        tilesM, tilesN, (int)(M % 8 == 0), gate);
   else if (split_ok && wmax && xmax && g_gemm_mode == HECKA_GEMM_AUTO)

@@ -303,6 +303,9 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
+        global LAST_BWD_KERNEL
+        tile = 256 if (B % 256 == 0 and B <= 1024 and os.environ.get('HECKA_BWD_TILE', '256') == '256') else 128
+        LAST_BWD_KERNEL = 'gram_bwd_x6_kernel<1, false, 0, %d>' % tile
     _GemmChain.leave(X.device, chain)
     return dX
 
