@@ -601,6 +601,22 @@ def run_uhsic():
     print('uhsic', rec['v0'], rec['v2'])
 
 
+def f32_twins():
+    """The reference's OWN float32 run of the train-step fixtures (same seeds, same inputs cast to float32): how far the
+    reference in float32 sits from the reference in float64 is the yardstick for every test tolerance above 1e-5.  Only
+    the outputs are kept (losses, predictions, gradients, running statistics): the inputs and weights are those of the
+    float64 fixture."""
+    for fn, name in ((run_resnet_step, 'resnet_train_step'), (run_svgd_step, 'svgd_step'), (run_wsvgd_step, 'wsvgd_step'),
+                     (run_hyper_step, 'hyper_train_step'), (run_hyper_toy_step, 'hyper_toy_train_step'),
+                     (run_learned_step, 'learned_step'), (run_fsvgd_step, 'fsvgd_step'))[(5 if '--f32-twins-rest' in sys.argv else 0):]:
+        fn(torch.float32, 'f32')
+        path = os.path.join(OUT, '%s_f32.npz' % name)
+        z = np.load(path, allow_pickle=False)
+        keep = {k: z[k] for k in z.files if not (k.startswith('w:') or k in ('X', 'Y', 'config'))}
+        np.savez_compressed(path, **keep)
+        print(name, 'f32 twin:', len(keep), 'arrays,', os.path.getsize(path) // 1024, 'KiB')
+
+
 def main():
     mk = _import_reference()
     if '--uhsic-only' in sys.argv:
@@ -619,9 +635,13 @@ def main():
         run_hyper_step(torch.float64, 'f64')
         run_hyper_toy_step(torch.float64, 'f64')
         return
+    if '--f32-twins' in sys.argv or '--f32-twins-rest' in sys.argv:
+        f32_twins()
+        return
     for dtype, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
         run_train_step(dtype, tag)
         run_lenet_step(dtype, tag)
+    f32_twins()
     run_resnet_step(torch.float64, 'f64')
     run_svgd_step(torch.float64, 'f64')
     run_wsvgd_step(torch.float64, 'f64')

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import Yardstick, golden_cases, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +42,32 @@ def test_model_kernel_matches_reference_golden(name):
     ref = R.run_config(rec['config'], xo)
     track = OrderedDict()
     out = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
+    # against the fixture itself (fp64 reference on the UNROUNDED inputs) the yardstick is the reference's own float32 run
+    # of the same case (<name>_f32.npz): its deviation from the fp64 run is what float32 inputs + arithmetic cost
+    f32 = load_golden(name, 'f32')
+    ref32 = lambda key: max(RTOL, _relerr(f32[key], rec[key]))   # noqa: E731
+    if name == 'he_lin_none':
+        # reduction 'none' keeps the diagonal pairs (i, i): cos = n^2 / (n + eps)^2 -> theta = arccos(1 - O(eps)) and the
+        # float32 autograd coefficient 1/d^2 - n/d^3 cancels - ill-conditioned in the reference itself.  Off-diagonal
+        # entries and the gradient that flows through them are held to 1e-5; the diagonal to the reference's own
+        # float32 deviation.
+        M = out.shape[0]
+        off = ~torch.eye(M, dtype=torch.bool)
+        up = torch.from_numpy(rec['upstream'])
+        o, r = out.detach().cpu().double(), ref.detach()
+        assert float((o - r)[off].abs().max() / r[off].abs().max()) <= RTOL
+        assert float((o - r)[~off].abs().max() / r[~off].abs().max()) <= ref32('out')
+        (out * (up * off).float().to(dev)).sum().backward(retain_graph=True)
+        (ref * (up * off)).sum().backward(retain_graph=True)
+        for i, x in enumerate(xs):
+            assert _relerr(x.grad.cpu().numpy(), xo[i].grad.numpy()) <= RTOL, 'layer %d (off-diagonal upstream)' % i
+            x.grad = None
+            xo[i].grad = None
+        (out * up.float().to(dev)).sum().backward()
+        (ref * up).sum().backward()
+        for i, x in enumerate(xs):
+            assert _relerr(x.grad.cpu().numpy(), xo[i].grad.numpy()) <= ref32('dx%d' % i), 'layer %d' % i
+        return
     if out.ndim == 0:
         out.backward()
         ref.backward()
@@ -49,15 +75,13 @@ def test_model_kernel_matches_reference_golden(name):
         up = torch.from_numpy(rec['upstream'])
         (out * up.float().to(dev)).sum().backward()
         (ref * up).sum().backward()
-    # the diagonal pair (i,i) of reduction='none' is ill-conditioned in fp32 (see test_oracle_golden)
-    tol = 5e-3 if name == 'he_lin_none' else RTOL
-    assert _relerr(out.detach().cpu().numpy(), ref.detach().numpy()) <= tol
-    assert _relerr(out.detach().cpu().numpy(), rec['out']) <= max(tol, 1e-4)
+    assert _relerr(out.detach().cpu().numpy(), ref.detach().numpy()) <= RTOL
+    assert _relerr(out.detach().cpu().numpy(), rec['out']) <= ref32('out')
     for i, x in enumerate(xs):
-        assert _relerr(x.grad.cpu().numpy(), xo[i].grad.numpy()) <= (2e-2 if name == 'he_lin_none' else RTOL), 'layer %d' % i
+        assert _relerr(x.grad.cpu().numpy(), xo[i].grad.numpy()) <= RTOL, 'layer %d' % i
         if 'gram%d' % i in rec:
             g = track['layer_track'][i]['gram'].cpu().numpy()
-            assert _relerr(g, rec['gram%d' % i]) <= 1e-4
+            assert _relerr(g, rec['gram%d' % i]) <= ref32('gram%d' % i)
 
 
 @pytest.mark.parametrize('M,B,P', [(3, 37, 19), (5, 300, 84), (2, 130, 10), (4, 128, 256), (2, 257, 515), (1, 8, 4)])
@@ -423,11 +447,16 @@ def test_toy_train_step_matches_reference_golden():
     assert list(track['feats_ind'].keys()) == json.loads(str(z['feat_keys']))
     track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
     track['loss'].backward()
-    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 1e-5
-    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
-    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    _check_step(Yardstick('toy_train_step'), track, hyper)
+
+
+def _check_step(yard, track, hyper, keys=('pred', 'ind_rep_loss', 'loss')):
+    """Every output of a training step against the float64 fixture, each held to max(1e-5, the deviation of the
+    reference's own float32 run of that quantity) - conftest.Yardstick."""
+    for key in keys:
+        yard.check(key, track[key].detach().cpu().numpy())
     for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 5e-5, k
+        yard.check('g:' + k, v.grad.cpu().numpy())
 
 
 CONV_CASES = ['conv_shared_gamma', 'conv_member_torch_nobias', 'conv_dilated_rect', 'conv_same_even', 'conv_reflect_1x1']
@@ -483,11 +512,7 @@ def test_lenet_train_step_matches_reference_golden():
     assert [list(v.shape) for v in track['feats_ind'].values()] == json.loads(str(z['feat_shapes']))
     track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
     track['loss'].backward()
-    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 1e-5
-    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
-    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
-    for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 5e-5, k
+    _check_step(Yardstick('lenet_train_step'), track, hyper)
 
 
 @pytest.mark.parametrize('shape,affine,training', [((3, 6, 5, 7, 4), True, True), ((2, 9, 4, 3, 3), False, True),
@@ -554,15 +579,76 @@ def test_resnet_train_step_matches_reference_golden():
     assert [list(v.shape) for v in track['feats_ind'].values()] == json.loads(str(z['feat_shapes']))
     track = method(types.SimpleNamespace(training=True), track['params'], [], track, X, Y, step=int(z['step']))
     track['loss'].backward()
-    assert _relerr(track['pred'].detach().cpu().numpy(), z['pred']) <= 2e-5
-    assert abs(track['ind_rep_loss'].item() - float(z['ind_rep_loss'])) <= 2e-5 * abs(float(z['ind_rep_loss']))
-    assert abs(track['loss'].item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
-    for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+    yard = Yardstick('resnet_train_step')
+    _check_step(yard, track, hyper)
     after = hyper.state_dict()
     for k in z.files:
-        if k.startswith('after:'):
-            assert _relerr(after[k[6:]].cpu().numpy(), z[k]) <= 2e-5 or np.abs(z[k]).max() == 0, k
+        if k.startswith('after:') and np.abs(z[k]).max() > 0:
+            yard.check(k, after[k[6:]].cpu().numpy())
+
+
+@pytest.mark.parametrize('B', [128, 6])
+def test_resnet_step_with_bf16_features_matches_oracle_on_rounded_features(B):
+    """BASELINE configs[2] says bf16: the ResNet18 ensemble of the fixture above, tracked block features cast to bf16 on
+    their way into the HE loss (the reference itself has no bf16 switch - SURVEY.md F6 - so the oracle is the
+    restatement in fp64 on the bf16-ROUNDED features, north_star tolerance rel 1e-2).  B = 128: the x16 kernels read the
+    bf16 features natively (P = C H W is a multiple of 128 for the block features; the 10 logits take the up-cast);
+    B = 6 (the fixture batch): everything through the up-cast.  Checked: the loss, dLoss/dfeature for every tracked
+    layer, and that the parameter gradients of the whole step stay within 1e-2 of the fp32-feature step's."""
+    import json
+    import os
+    import types
+    from collections import OrderedDict
+    import hyper_amd.target  # noqa: F401
+    from hyper_amd.generators import build_generator
+    from hyper_amd.diversity.methods import build_method
+    from oracle import hecka_ref as R
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'resnet_train_step_f64.npz'), allow_pickle=False)
+    cfg = json.loads(str(z['config']))
+    dev = _dev()
+    hyper = build_generator(cfg['hyper'])
+    hyper.load_state_dict({k[2:]: torch.from_numpy(z[k]).float() for k in z.files if k.startswith('w:')})
+    hyper = hyper.to(dev)
+    method = build_method(cfg['method']).to(dev)
+    g = torch.Generator().manual_seed(12)
+    X = (torch.from_numpy(z['X']).float() if B == 6 else torch.randn(B, 3, 16, 16, generator=g)).to(dev)
+    Y = (torch.from_numpy(z['Y']) if B == 6 else torch.randint(0, 10, (B,), generator=g)).to(dev)
+    trainer = types.SimpleNamespace(training=True)
+
+    def step(cast):
+        hyper.zero_grad()
+        sd = {k: v.clone() for k, v in hyper.state_dict().items()}     # the step updates the running statistics
+        track = hyper(params=list(range(3)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
+        feats = track['feats_ind']
+        if cast:
+            track['feats_ind'] = OrderedDict((k, v.bfloat16()) for k, v in feats.items())
+        track = method(trainer, track['params'], [], track, X, Y, step=int(z['step']))
+        track['loss'].backward()
+        hyper.load_state_dict(sd)
+        return track, feats, {k: v.grad.clone() for k, v in hyper.named_parameters()}
+
+    t32, _, g32 = step(False)
+    t16, feats, g16 = step(True)
+    # (1) the loss term itself on bf16 leaves against the oracle on the rounded values
+    leaves = [v.detach().bfloat16().requires_grad_(True) for v in feats.values()]
+    rep = method.model_kernel(None, OrderedDict((k, x) for k, x in zip(feats.keys(), leaves)), None, OrderedDict())
+    rep.backward()
+    xo = [x.detach().double().requires_grad_(True) for x in leaves]
+    ref = R.run_config(cfg['method']['model_kernel'], xo)
+    ref.backward()
+    assert abs(rep.item() - ref.item()) <= 1e-2 * abs(ref.item())
+    assert abs(t16['ind_rep_loss'].item() - ref.item()) <= 1e-2 * abs(ref.item())
+    for x, o in zip(leaves, xo):
+        if float(o.grad.abs().max()) > 0:      # (the first tracked layer has weight 0 in configs/cifar10/ens/he-lin.yml)
+            assert x.grad.dtype == torch.bfloat16
+            assert float((x.grad.double() - o.grad).abs().max() / o.grad.abs().max()) <= 1e-2
+    # (2) the whole step: bf16 features move the parameter gradients by no more than the north_star tolerance
+    for k in g32:
+        scale = float(g32[k].abs().max())
+        if scale > 0:
+            assert float((g16[k] - g32[k]).abs().max()) <= 1e-2 * scale, k
+    assert abs(t16['loss'].item() - t32['loss'].item()) <= 1e-2 * abs(t32['loss'].item())
 
 
 @pytest.mark.parametrize('M,B,dims', [(8, 128, (64, 272, 32)), (5, 256, (48, 16))])
@@ -633,9 +719,10 @@ def test_svgd_step_matches_reference_golden():
     track = hyper(params=list(range(5)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
     track = method(trainer, track['params'], [], track, X, Y, step=0)
     loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
-    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    yard = Yardstick('svgd_step')
+    yard.check('loss', loss.item())
     for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+        yard.check('g:' + k, v.grad.cpu().numpy())
 
 
 def test_ckas_metric_from_loss_byproducts_matches_oracle():
@@ -1082,10 +1169,11 @@ def test_weight_space_svgd_step_matches_reference_golden():
     track = method(trainer, track['params'], [], track, X, Y, step=0)
     loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
     kern = method.model_kernel(track['params'], track['feats_ind'], track['pred_ind'], track)
-    assert _relerr(kern.detach().cpu().numpy(), z['kern']) <= 2e-5
-    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
+    yard = Yardstick('wsvgd_step')
+    yard.check('kern', kern.detach().cpu().numpy())
+    yard.check('loss', loss.item())
     for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+        yard.check('g:' + k, v.grad.cpu().numpy())
 
 
 def test_accuracy_metric_and_inlier_outlier_entropy():
@@ -1145,10 +1233,10 @@ def test_function_svgd_step_matches_reference_golden():
     track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=0)
     track = method(trainer, track['params'], [], track, X, Y, step=0)
     loss, _ = method.backward(trainer, track['params'], [], track, X, Y)
-    assert abs(loss.item() - float(z['loss'])) <= 2e-5 * abs(float(z['loss']))
-    worst = max(_relerr(v.grad.cpu().numpy(), z['g:' + k]) for k, v in hyper.named_parameters())
-    print('function svgd: worst gradient error %.2e' % worst)
-    assert worst <= 2e-5
+    yard = Yardstick('fsvgd_step')
+    yard.check('loss', loss.item())
+    for k, v in hyper.named_parameters():
+        yard.check('g:' + k, v.grad.cpu().numpy())
 
 
 def test_learnable_hyperparameters_step_matches_reference_golden():
@@ -1178,11 +1266,9 @@ def test_learnable_hyperparameters_step_matches_reference_golden():
     track = hyper(params=list(range(6)), x=X, sample_params=True, ret_params=True, feature_split=True, ood_N=ood)
     track = method(types.SimpleNamespace(training=True), track['params'], [], track, X[:-ood], Y, step=int(z['step']))
     track['loss'].backward()
-    for key in ('loss', 'ind_rep_loss', 'ood_rep_loss'):
-        assert abs(track[key].item() - float(z[key])) <= 2e-5 * abs(float(z[key])), key
-    for k, v in hyper.named_parameters():
-        assert _relerr(v.grad.cpu().numpy(), z['g:' + k]) <= 1e-4, k
+    yard = Yardstick('learned_step')
+    _check_step(yard, track, hyper, keys=('loss', 'ind_rep_loss', 'ood_rep_loss'))
     got = dict(method.named_parameters())
     for k in [k[3:] for k in z.files if k.startswith('mg:')]:
         assert got[k].grad is not None, k
-        assert _relerr(got[k].grad.cpu().numpy(), z['mg:' + k]) <= 1e-4, k
+        yard.check('mg:' + k, got[k].grad.cpu().numpy())
