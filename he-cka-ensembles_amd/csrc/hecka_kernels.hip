@@ -2191,13 +2191,9 @@ extern "C" {
 
 int hecka_version(void) { return 5; }
 
-static int g_gemm_mode = 0;
-int hecka_set_gemm_mode(int mode) {
-  if (mode != HECKA_GEMM_AUTO && mode != HECKA_GEMM_FP32 && mode != HECKA_GEMM_BF16X6) return fail(HECKA_EINVAL, "set_gemm_mode: unknown mode%s");
-  g_gemm_mode = mode;
-  return HECKA_OK;
+static inline bool gemm_mode_ok(int mode) {
+  return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
 }
-int hecka_get_gemm_mode(void) { return g_gemm_mode; }
 const char* hecka_last_error(void) { return g_err; }
 
 int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* xmax, void* stream) {
@@ -2242,8 +2238,10 @@ int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar
 }
 
 int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P, float* C,
-                          float* cvec, void* stream) {
+                          float* cvec, int gemm_mode, void* stream) {
   clear_error();
+  if (!gemm_mode_ok(gemm_mode)) return fail(HECKA_EINVAL, "gram_center: unknown gemm_mode%s");
+  const int g_gemm_mode = gemm_mode;
   if (!X || !sbar || !C || !cvec) return fail(HECKA_EINVAL, "gram_center: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_center: non-positive size%s");
   if (M > 65535) return fail(HECKA_EINVAL, "gram_center: M > 65535%s");
@@ -2289,7 +2287,7 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* ws, size_t ws_bytes, void* stream);
+                                  float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream);
 
 // Split-K plan of a multi-layer Gram launch: none while the unsplit grid already fills the GPU twice over (1024
 // workgroups); otherwise every layer is cut into pieces of about d* features, d* = total depth / 1024 (at least 1024),
@@ -2327,25 +2325,27 @@ size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P
 }
 
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
-                                int B, const int* P, float* const* C, float* const* cvec, void* stream) {
+                                int B, const int* P, float* const* C, float* const* cvec, int gemm_mode, void* stream) {
   return gram_center_multi_impl(L, reinterpret_cast<const void* const*>(X), HECKA_DT_F32, sbar, xmax, M, B, P, C, cvec,
-                                nullptr, 0, stream);
+                                nullptr, 0, gemm_mode, stream);
 }
 
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* ws, size_t ws_bytes, void* stream) {
+                                float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream) {
   if (dtype != HECKA_DT_F32 && dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) {
     clear_error();
     return fail(HECKA_EINVAL, "gram_center_multi_x16: unknown dtype%s");
   }
-  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, stream);
+  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, gemm_mode, stream);
 }
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* ws, size_t ws_bytes, void* stream) {
+                                  float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream) {
   clear_error();
+  if (!gemm_mode_ok(gemm_mode)) return fail(HECKA_EINVAL, "gram_center_multi: unknown gemm_mode%s");
+  const int g_gemm_mode = gemm_mode;
   const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
   if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
@@ -2877,7 +2877,7 @@ static int bgemm_x3_nsplit(int batch, int rows, int cols, int K) {
 }
 
 int hecka_bgemm_x3_eligible(int batch, int rows, int cols, int K) {
-  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && cols > 0 && K > 0 && rows % 64 == 0 && cols % 128 == 0 &&
+  return batch > 0 && rows > 0 && cols > 0 && K > 0 && rows % 64 == 0 && cols % 128 == 0 &&
          K % kX6BK == 0 && (long long)rows * K < (1ll << 30) && (long long)cols * K < (1ll << 30) &&
          (long long)batch * (rows / 64) * (cols / 128) < (1ll << 31);
 }
@@ -2932,7 +2932,7 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
 
 int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, int W) {
   const long long S = (long long)H * W, Q = (long long)N * S;
-  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && rows > 0 && K > 0 && N > 0 && Cin > 0 && H > 0 && W > 0 &&
+  return batch > 0 && rows > 0 && K > 0 && N > 0 && Cin > 0 && H > 0 && W > 0 &&
          rows % 64 == 0 && Q % 128 == 0 && K % kX6BK == 0 && (long long)rows * K < (1ll << 30) &&
          (long long)N * Cin * S < (1ll << 30) && (long long)N * rows * S < (1ll << 31) &&
          (long long)batch * (rows / 64) * (Q / 128) < (1ll << 31);
@@ -2970,7 +2970,7 @@ static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
 
 int hecka_conv_wgrad_x3_eligible(int batch, int O, int Rp, int N, int C, int H, int W) {
   const long long S = (long long)H * W, Q = (long long)N * S;
-  return g_gemm_mode == HECKA_GEMM_AUTO && batch > 0 && O > 0 && Rp > 0 && N > 0 && C > 0 && H > 0 && W > 0 && O % 64 == 0 &&
+  return batch > 0 && O > 0 && Rp > 0 && N > 0 && C > 0 && H > 0 && W > 0 && O % 64 == 0 &&
          Rp % 128 == 0 && Q % 16 == 0 && W % 4 == 0 && (W >= 16 ? W % 16 == 0 : 16 % W == 0) &&
          (long long)N * O * S < (1ll << 30) && (long long)N * C * S < (1ll << 30) && Q < (1ll << 31) &&
          (long long)batch * O * Rp < (1ll << 31);
@@ -3243,8 +3243,10 @@ int hecka_crater_maxpool2_f32(const float* x, const float* dy, float* out, long 
 }
 
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, const float* gate, int M, int B,
-                       int P, float* dX, void* stream) {
+                       int P, float* dX, int gemm_mode, void* stream) {
   clear_error();
+  if (!gemm_mode_ok(gemm_mode)) return fail(HECKA_EINVAL, "gram_bwd: unknown gemm_mode%s");
+  const int g_gemm_mode = gemm_mode;
   if (!W || !X || !dX) return fail(HECKA_EINVAL, "gram_bwd: null pointer%s");
   if (M <= 0 || B <= 0 || P <= 0 || M > 65535) return fail(HECKA_EINVAL, "gram_bwd: bad size%s");
   GemmOperands g;
@@ -3298,10 +3300,11 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
 }
 
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate, int M,
-                       int B, int P, void* dX, void* stream) {
+                       int B, int P, void* dX, int gemm_mode, void* stream) {
   if (dtype == HECKA_DT_F32)
-    return hecka_gram_bwd_f32(W, static_cast<const float*>(X), wmax, xmax, gate, M, B, P, static_cast<float*>(dX), stream);
+    return hecka_gram_bwd_f32(W, static_cast<const float*>(X), wmax, xmax, gate, M, B, P, static_cast<float*>(dX), gemm_mode, stream);
   clear_error();
+  const int g_gemm_mode = gemm_mode;
   if (dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) return fail(HECKA_EINVAL, "gram_bwd_x16: unknown dtype%s");
   if (!W || !X || !dX || !wmax || !xmax) return fail(HECKA_EINVAL, "gram_bwd_x16: null pointer (wmax and xmax are required)%s");
   if (M <= 0 || B <= 0 || P <= 0) return fail(HECKA_EINVAL, "gram_bwd_x16: bad size%s");

@@ -15,10 +15,8 @@ _vp, _i, _ll, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes
 SIGNATURES = {
     'hecka_version': (_i, []),
     'hecka_last_error': (ctypes.c_char_p, []),
-    'hecka_set_gemm_mode': (_i, [_i]),
-    'hecka_get_gemm_mode': (_i, []),
     'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
-    'hecka_gram_center_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'hecka_gram_center_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
     'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
     'hecka_pairwise_noalloc_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp]),
@@ -37,12 +35,12 @@ SIGNATURES = {
     'hecka_bgemm_splitk_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, ctypes.c_size_t, _vp]),
     'hecka_im2col_f32': (_i, [_vp] + [_i] * 14 + [_vp, _vp]),
     'hecka_col2im_f32': (_i, [_vp] + [_i] * 14 + [_vp, _vp]),
-    'hecka_gram_center_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    'hecka_gram_center_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'hecka_wbound_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'hecka_colmean_x16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     'hecka_gram_center_multi_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
-    'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'hecka_head_fwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_head_bwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_coef_gamma_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -69,7 +67,7 @@ SIGNATURES = {
     'hecka_combine_slice_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'hecka_batchnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
-    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
 }
 
 

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 import torch.nn.init as init
 from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 
-from .. import _lib
+from .. import _lib, ops
 from ..net import activation
 from .linear import _absmax_rows, _bgemm, _bgemm_x3, _x3_eligible
 from .norm import cached_absmax
@@ -73,7 +73,7 @@ def _conv_x3_ok(geom, M, rows, K, N, Cin, H, W):
     kh, kw, sh, sw, ph, pw, dh, dw = geom
     return (os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0' and os.environ.get('HECKA_CONV_X3', '1') != '0'
             and sh == 1 and sw == 1 and dh == 1 and dw == 1 and 2 * ph == kh - 1 and 2 * pw == kw - 1
-            and bool(_lib.lib().hecka_conv_x3_eligible(M, rows, K, N, Cin, H, W)))
+            and ops.get_gemm_mode() == 0 and bool(_lib.lib().hecka_conv_x3_eligible(M, rows, K, N, Cin, H, W)))
 
 
 def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride):
@@ -111,6 +111,7 @@ def _conv_direct(x, x_stride, wt, bias, bias_scale, M, N, C, H, W, O, kh, kw, pa
     return y
 
 
+@ops.mode_aware
 class BatchedConv2d(torch.autograd.Function):
     """y[m] = conv2d(x[m] | x, scale * W[m], bias_scale * b[m]);  x [M,N,C,H,W] or [N,C,H,W] (shared),
     W [M,O,C,kh,kw], b [M,O] | None  ->  y [M,N,O,Ho,Wo].  groups = 1, zero padding."""
@@ -220,7 +221,8 @@ class BatchedConv2d(torch.autograd.Function):
         L = _lib.lib()
         if (ctx.needs_input_grad[1] and not has_bias and dymax is not None and geom[2:] == (1, 1, geom[4], geom[5], 1, 1)
                 and 2 * geom[4] == kh - 1 and 2 * geom[5] == kw - 1 and os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0'
-                and os.environ.get('HECKA_CONV_X3', '1') != '0' and L.hecka_conv_wgrad_x3_eligible(M, O, Rp, N, C, H, Wd)):
+                and os.environ.get('HECKA_CONV_X3', '1') != '0' and ops.get_gemm_mode() == 0
+                and L.hecka_conv_wgrad_x3_eligible(M, O, Rp, N, C, H, Wd)):
             # weight gradient with both operands implicit: dy as it lies (NCHW), patches gathered in the kernel
             dWp = torch.empty((M, O, Rp), device=dy.device, dtype=torch.float32)
             nbytes = L.hecka_conv_wgrad_x3_workspace_bytes(M, O, Rp, N, C, H, Wd)

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 import torch.nn.init as init
 
-from .. import _lib
+from .. import _lib, ops
 from ..net import activation
 from .module import ParametersGroup, register_gen_module
 
@@ -40,7 +40,8 @@ def _absmax_rows(V, rows):
 
 
 def _x3_eligible(batch, rows, cols, K):
-    return os.environ.get('HECKA_CONV_X3', '1') != '0' and bool(_lib.lib().hecka_bgemm_x3_eligible(batch, rows, cols, K))
+    return (os.environ.get('HECKA_CONV_X3', '1') != '0' and ops.get_gemm_mode() == 0      # fp16-split only in HECKA_GEMM_AUTO
+            and bool(_lib.lib().hecka_bgemm_x3_eligible(batch, rows, cols, K)))
 
 
 def _bgemm_x3(A, B, batch, rows, cols, K, sA, sB, nn, alpha, amaxA, amaxB, amaxB_stride):
@@ -55,6 +56,7 @@ def _bgemm_x3(A, B, batch, rows, cols, K, sA, sB, nn, alpha, amaxA, amaxB, amaxB
     return out
 
 
+@ops.mode_aware
 class BatchedLinear(torch.autograd.Function):
     """y[m] = scale * x[m] W[m]^T + bias_scale * b[m];  x [M,N,I] (or [N,I], shared), W [M,O,I], b [M,O] | None."""
 

@@ -18,13 +18,53 @@ LAST_BWD_KERNEL = None     # name of the kernel the last dX launch took (bench.p
 EXCHANGED_BYTES = 0        # bytes this rank handed to collectives (hyper_amd/parallel.py adds to it; bench.py reports it)
 
 
+# ---- arithmetic of the two large GEMMs (include/hecka.h HECKA_GEMM_*): 0 auto (f16x3), 1 fp32 MFMA, 2 bf16x6 ---------------
+# A per-call argument of the C-ABI; here: a process default (HECKA_GEMM_MODE, set_gemm_mode) that `with gemm_mode(m):`
+# overrides for the calling thread.  Autograd nodes remember the mode of their forward and use it in backward (which
+# runs on another thread), so two kernels in one process may differ.
+_MODE_NAMES = (0, 1, 2)
+_mode_default = [int(os.environ.get('HECKA_GEMM_MODE', '0'))]
+_mode_tls = threading.local()
+
+
 def set_gemm_mode(mode):
-    """Arithmetic of the two large GEMMs (include/hecka.h HECKA_GEMM_*): 0 auto (f16x3), 1 fp32 MFMA, 2 bf16x6."""
-    _lib.check(_lib.lib().hecka_set_gemm_mode(int(mode)), 'set_gemm_mode')
+    if int(mode) not in _MODE_NAMES:
+        raise ValueError('gemm mode must be 0 (auto: f16x3), 1 (fp32 MFMA) or 2 (bf16x6)')
+    _mode_default[0] = int(mode)
 
 
 def get_gemm_mode():
-    return int(_lib.lib().hecka_get_gemm_mode())
+    m = getattr(_mode_tls, 'mode', None)
+    return _mode_default[0] if m is None else m
+
+
+@contextlib.contextmanager
+def gemm_mode(mode):
+    if mode is not None and int(mode) not in _MODE_NAMES:
+        raise ValueError('gemm mode must be 0 (auto: f16x3), 1 (fp32 MFMA) or 2 (bf16x6)')
+    prev = getattr(_mode_tls, 'mode', None)
+    _mode_tls.mode = None if mode is None else int(mode)
+    try:
+        yield
+    finally:
+        _mode_tls.mode = prev
+
+
+def mode_aware(cls):
+    """Class decorator for autograd Functions that launch the large GEMMs: backward runs on autograd's thread, so the
+    node remembers the GEMM mode its forward ran under and re-enters it."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args, **kwargs):
+        ctx._gemm_mode = get_gemm_mode()
+        return fwd(ctx, *args, **kwargs)
+
+    def backward(ctx, *grads):
+        with gemm_mode(ctx._gemm_mode):
+            return bwd(ctx, *grads)
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
 
 
 # ---- gradient gate ------------------------------------------------------------------------------------------------
@@ -88,7 +128,7 @@ def native16_eligible(Xs):
             return False
         if X.shape[2] % 128 or X.shape[2] == 0 or B * X.shape[2] * 2 >= 2 ** 32:
             return False
-    return _lib.lib().hecka_get_gemm_mode() == 0
+    return get_gemm_mode() == 0
 
 
 def _features(X):
@@ -160,7 +200,7 @@ def centered_gram(X, return_xmax=False, out=None):
     st = _stream()
     _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
     gate = _GemmChain.enter(X.device)
-    _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), _p(xmax), M, B, P, _p(C), _p(cvec), st), 'gram_center')
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), _p(xmax), M, B, P, _p(C), _p(cvec), get_gemm_mode(), st), 'gram_center')
     _GemmChain.leave(X.device, gate)
     return (C, cvec, xmax) if return_xmax else (C, cvec)
 
@@ -179,7 +219,7 @@ def multi_gram_eligible(Xs):
             return False
         if X.shape[2] % 16 or B * X.shape[2] * 4 >= 2 ** 32:
             return False
-    return B % 128 == 0 and _lib.lib().hecka_get_gemm_mode() != 1
+    return B % 128 == 0 and get_gemm_mode() != 1
 
 
 def centered_gram_multi(Xs):
@@ -214,7 +254,7 @@ def centered_gram_multi(Xs):
     _lib.check(L.hecka_gram_center_multi_x16(
         n, ptrs([Xs[i] for i in order]), dt, ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
         Ps, ptrs([out[i][0] for i in order]), ptrs([out[i][1] for i in order]),
-        _p(ws) if ws is not None else None, nbytes, st), 'gram_center_multi')
+        _p(ws) if ws is not None else None, nbytes, get_gemm_mode(), st), 'gram_center_multi')
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
 
 
@@ -299,7 +339,7 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
         e0.record()
     _lib.check(_lib.lib().hecka_gram_bwd_x16(_p(W), _p(X), _DTYPE_CODE[X.dtype], _p(wmax) if wmax is not None else None,
                                              _p(xmax) if xmax is not None else None, _gp(gate), Ma, B, P, _p(dX),
-                                             _stream()), 'gram_bwd')
+                                             get_gemm_mode(), _stream()), 'gram_bwd')
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
@@ -392,6 +432,7 @@ def combine_full(A, C, gamma, detach_diag):
     return W
 
 
+@mode_aware
 class DiversityLayers(torch.autograd.Function):
     """ALL tracked layers of a `model_layers` loss in one autograd node (linear centred Grams, he / cka heads, mean / sum
     reduction, host-float layer weights):
@@ -475,6 +516,7 @@ def diversity_layers(Xs, specs, scales, detach_diag=True, pre=None, gspecs=None)
                                   list(gspecs) if gspecs is not None else None), *Xs)
 
 
+@mode_aware
 class CenteredGramPairwise(torch.autograd.Function):
     """X [M,B,P] -> (S [M,M], nsq [M], C [M,B,B]).
 
@@ -548,6 +590,7 @@ def pairwise_inner_ad(V, left_only=False):
     return PairwiseInner.apply(V, left_only)
 
 
+@mode_aware
 class LinearGram(torch.autograd.Function):
     """X [M,B,P] -> K = X X^T (value of the diagonal kept; its gradient dropped when detach_diag).
     backward: dX = (dK + dK^T, diag masked) X."""
@@ -561,7 +604,7 @@ class LinearGram(torch.autograd.Function):
         zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
         K = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
         cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
-        _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(K), _p(cvec), _stream()), 'gram')
+        _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(K), _p(cvec), get_gemm_mode(), _stream()), 'gram')
         ctx.save_for_backward(X)
         ctx.detach_diag = bool(detach_diag)
         ctx.gate = current_gate()
@@ -577,7 +620,7 @@ class LinearGram(torch.autograd.Function):
         dX = torch.empty_like(X)
         st = _stream()
         _lib.check(L.hecka_symmetrize_f32(_p(dK), M, B, int(ctx.detach_diag), _p(W), st), 'symmetrize')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), get_gemm_mode(), st), 'gram_bwd')
         return dX, None
 
 
@@ -645,7 +688,7 @@ def raw_gram(X):
     zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
     G = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
     scratch = torch.empty((M, B), device=X.device, dtype=torch.float32)
-    _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(G), _p(scratch), _stream()), 'gram')
+    _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(G), _p(scratch), get_gemm_mode(), _stream()), 'gram')
     return G
 
 
@@ -683,10 +726,11 @@ def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec, gate=None):
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), None, st), 'combine')
     _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(C), _p(rmean), _p(gdiag), _p(hband), M, B, gspec.kind, st),
                'gram_transform_bwd')
-    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(gate), M, B, P, _p(dX), st), 'gram_bwd')
+    _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(gate), M, B, P, _p(dX), get_gemm_mode(), st), 'gram_bwd')
     return dX
 
 
+@mode_aware
 class DiversityLayer(torch.autograd.Function):
     """One tracked layer of the diversity loss, entirely in libhecka:
          X [M,B,P] -> centred Gram C -> S = <C_i,C_j> -> cos -> (energy) -> value matrix / reduced scalar.
@@ -786,6 +830,7 @@ def head_backward(S, nsq, row_offset, spec, up_scalar, scale, up_mat=None):
     return A
 
 
+@mode_aware
 class TransformedGram(torch.autograd.Function):
     """Un-fused functional API: X -> K' (cossim / rbf Gram, not centred); backward dK' -> dX."""
 
@@ -816,7 +861,7 @@ class TransformedGram(torch.autograd.Function):
             _lib.check(L.hecka_symmetrize_f32(_p(dK.contiguous()), M, B, 1, _p(W), st), 'symmetrize')
         _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(K), None, _p(gdiag), _p(hband), M, B, ctx.gspec.kind, st),
                    'gram_transform_bwd')
-        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), st), 'gram_bwd')
+        _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(ctx.gate), M, B, P, _p(dX), get_gemm_mode(), st), 'gram_bwd')
         return dX, None, None
 
 

@@ -148,10 +148,17 @@ class _SlicedLayers(torch.autograd.Function):
         ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
         ctx.geom = (world, rank, Ml, B, bounds, ns)
         ctx.gate = getattr(backend, 'current_gate', lambda: None)()     # ops.grad_gate: a masked NaN term gives dX = 0
+        ctx.mode = getattr(backend, 'get_gemm_mode', lambda: None)()
         return total.clone()
 
     @staticmethod
     def backward(ctx, dloss):
+        import contextlib
+        with getattr(ctx.backend, 'gemm_mode', lambda m: contextlib.nullcontext())(ctx.mode):   # forward's GEMM mode (another thread)
+            return _SlicedLayers._backward(ctx, dloss)
+
+    @staticmethod
+    def _backward(ctx, dloss):
         be, group = ctx.backend, ctx.group
         world, rank, Ml, B, bounds, ns = ctx.geom
         r0, n_r, N2 = rank * Ml, ns[rank], B * B
@@ -232,10 +239,17 @@ class _GatheredLayers(torch.autograd.Function):
         _all_reduce(total, group)
         ctx.saved, ctx.backend, ctx.r0, ctx.detach = saved, backend, r0, detach
         ctx.gate = getattr(backend, 'current_gate', lambda: None)()
+        ctx.mode = getattr(backend, 'get_gemm_mode', lambda: None)()
         return total
 
     @staticmethod
     def backward(ctx, dloss):
+        import contextlib
+        with getattr(ctx.backend, 'gemm_mode', lambda m: contextlib.nullcontext())(ctx.mode):
+            return _GatheredLayers._backward(ctx, dloss)
+
+    @staticmethod
+    def _backward(ctx, dloss):
         dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
         grads = []
         for X, C_all, cv_all, S, nsq, spec, scale, xmax in ctx.saved:

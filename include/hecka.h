@@ -30,8 +30,9 @@ extern "C" {
 int hecka_version(void);
 const char* hecka_last_error(void);
 
-/* Arithmetic of the two large GEMMs (hecka_gram_center_f32, hecka_gram_bwd_f32).  No counterpart in the reference
- * (torch.bmm picks its own algorithm); a process-wide tuning knob.  Interior shapes (B % 128 == 0 and P % 16 == 0
+/* Arithmetic of the two large GEMMs - the `gemm_mode` argument of hecka_gram_center_*, hecka_gram_bwd_*.  No counterpart
+ * in the reference (torch.bmm picks its own algorithm).  It is a per-call argument: the library holds no process-wide
+ * state, two callers in one process may use different modes.  Interior shapes (B % 128 == 0 and P % 16 == 0
  * resp. P % 128 == 0) run on the 16-bit matrix cores with fp32 operands split EXACTLY into 16-bit terms, partial
  * sums over 64 k folded into the running sum with round-to-nearest fp32 adds; other shapes use fp32 MFMA.
  *   HECKA_GEMM_AUTO (default): "f16x3" when the caller supplies the operands' absolute maxima (xmax / wmax below):
@@ -39,12 +40,12 @@ const char* hecka_last_error(void);
  *     scale 2^e comes from the maximum, so an element below 2^-17 of its member's maximum loses relative (not
  *     absolute) precision.  Measured error <= 6e-7 of sum|a.b| at K = 8192 (fp32 MFMA: 2.5e-6).  Without maxima:
  *     "bf16x6" - three bf16 terms (24 bits), six products, no scaling, no range assumption; error <= 4e-7.
- *   HECKA_GEMM_BF16X6: never f16x3.     HECKA_GEMM_FP32: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
+ *   HECKA_GEMM_BF16X6: never f16x3.     HECKA_GEMM_FP32: fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
+ * The fp16-split layer GEMMs (hecka_bgemm_x3_f32, hecka_conv_*_x3_f32) are separate entry points: a caller that wants
+ * fp32 MFMA there calls hecka_bgemm_f32 instead. */
 #define HECKA_GEMM_AUTO 0
 #define HECKA_GEMM_FP32 1
 #define HECKA_GEMM_BF16X6 2
-int hecka_set_gemm_mode(int mode);
-int hecka_get_gemm_mode(void);
 
 /* Column mean of each member's features: sbar[m,p] = (1/B) sum_b X[m,b,p].
  * First half of the fused replacement of center_gram (hyper/diversity/kernels.py:335-345):
@@ -60,7 +61,7 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* x
  * (hyper/diversity/model_kernels.py:84-123) and HEModelKernel.forward (:369-377).
  * xmax (may be NULL): [M] max |X[m]| from hecka_colmean_f32; enables f16x3 (see HECKA_GEMM_AUTO). */
 int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, int M, int B, int P,
-                          float* C, float* cvec, void* stream);
+                          float* C, float* cvec, int gemm_mode, void* stream);
 
 /* hecka_gram_center_f32 for L tracked layers (same M and B, their own P) in ONE launch: X / sbar / xmax / C / cvec are
  * HOST arrays of L device pointers (xmax, or any xmax[i], may be NULL), P a host array of L feature widths, layers
@@ -69,7 +70,7 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
  * ModelLayersKernel.forward (hyper/diversity/model_kernels.py:446-478) for the Gram stage: one layer alone leaves
  * the second scheduling round of the GPU three-quarters empty (M*10 workgroups on 512 slots at B = 512). */
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
-                                int B, const int* P, float* const* C, float* const* cvec, void* stream);
+                                int B, const int* P, float* const* C, float* const* cvec, int gemm_mode, void* stream);
 
 /* Pairwise inner products of vectorised Grams: S[i,j] = <Ca[i,:], Cb[j,:]>, Ca [Ma,K], Cb [Mb,K],
  * K = B*B.  Split-K over workgroups with a fixed-order (deterministic) second-stage sum.
@@ -338,9 +339,9 @@ int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar
 size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P);
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* ws, size_t ws_bytes, void* stream);
+                                float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream);
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate,
-                       int M, int B, int P, void* dX, void* stream);
+                       int M, int B, int P, void* dX, int gemm_mode, void* stream);
 
 /* dX[m] = W[m] X[m]   (W [M,B,B] symmetric, X [M,B,P]) — backward of torch.bmm(X, X^T)
  * (hyper/diversity/kernels.py:122).  wmax / xmax (may be NULL): [M] maxima from hecka_combine_f32 /
@@ -349,7 +350,7 @@ int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wm
  * drops a NaN repulsion term from the loss AND from the graph (hyper/diversity/methods.py:342-348: `if rep.isnan()` on the
  * host); here the caller sets *gate = 0 on the device instead, so that no 0 * NaN product reaches the feature gradients. */
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, const float* gate, int M, int B,
-                       int P, float* dX, void* stream);
+                       int P, float* dX, int gemm_mode, void* stream);
 
 #ifdef __cplusplus
 }

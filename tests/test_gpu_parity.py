@@ -172,10 +172,8 @@ def test_gemm_modes_against_fp64(M, B, P):
     dC = torch.einsum('ij,jab->iab', A.double(), Cref)
     Wd = (dC + dC.transpose(1, 2)) * (1 - torch.eye(B, dtype=torch.float64, device=dev))
     dref = Wd @ Xd
-    L = _lib.lib()
-    try:
-        for mode in (0, 2, 1):   # f16x3 (two fp16 terms, scaled by xmax / wmax), bf16x6, fp32 MFMA
-            assert L.hecka_set_gemm_mode(mode) == 0
+    for mode in (0, 2, 1):   # f16x3 (two fp16 terms, scaled by xmax / wmax), bf16x6, fp32 MFMA
+        with ops.gemm_mode(mode):
             C, cvec, xmax = ops.centered_gram(X, True)
             assert torch.equal(xmax, X.abs().amax(dim=(1, 2)))
             assert float((C.double() - Cref).abs().max() / Cref.abs().max()) <= 2e-6, mode
@@ -183,8 +181,36 @@ def test_gemm_modes_against_fp64(M, B, P):
             assert float((cvec.double() - cref).abs().max() / cref.abs().max()) <= 1e-5, mode
             dX = ops.gram_backward(A, C, cvec, X, True, xmax)
             assert float((dX.double() - dref).abs().max() / dref.abs().max()) <= 1e-5, mode
+
+
+def test_gemm_mode_travels_with_the_autograd_node():
+    """The GEMM arithmetic is a per-call argument of the C-ABI; `with ops.gemm_mode(m)` around the FORWARD is enough - the
+    node re-enters the mode in backward (autograd's thread).  Bit-equal to the same evaluation under a process default
+    of that mode, and two kernels with different modes coexist in one process."""
+    from collections import OrderedDict
+    from hyper_amd import ops
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    import bench
+    dev = _dev()
+    torch.manual_seed(8)
+    feats = [torch.randn(8, 128, p, device=dev) for p in (256, 128)]
+
+    def run(ctx_mode):
+        xs = [f.clone().requires_grad_(True) for f in feats]
+        kern = build_model_kernel(bench.CFG).to(dev)
+        with ops.gemm_mode(ctx_mode):
+            out = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+        out.backward()                       # outside the context
+        return out.detach(), [x.grad for x in xs]
+    res = {m: run(m) for m in (0, 1, 2)}
+    try:
+        for m in (1, 2):
+            ops.set_gemm_mode(m)
+            out, grads = run(None)
+            assert torch.equal(out, res[m][0]) and all(torch.equal(a, b) for a, b in zip(grads, res[m][1])), m
     finally:
-        L.hecka_set_gemm_mode(0)
+        ops.set_gemm_mode(0)
+    assert not torch.equal(res[0][1][0], res[1][1][0])     # the modes do differ in the last bits
 
 
 def test_f16x3_scaling_over_dynamic_range():
@@ -201,7 +227,7 @@ def test_f16x3_scaling_over_dynamic_range():
     Xd = X.double()
     K = Xd @ Xd.transpose(1, 2)
     Cref = K - K.mean(2, keepdim=True)
-    assert _lib.lib().hecka_get_gemm_mode() == 0
+    assert ops.get_gemm_mode() == 0
     C, cvec, xmax = ops.centered_gram(X, True)
     err = (C.double() - Cref).abs().amax(dim=(1, 2)) / Cref.abs().amax(dim=(1, 2))
     assert float(err.max()) <= 2e-6, err
@@ -257,20 +283,17 @@ def test_bench_workload_five_layers_against_fp64_oracle(style):
     assert [tuple(f.shape) for f in feats] == [(64, 512, p) for p in (512, 1024, 2048, 4096, 8192)]
     for cfg in (bench.CFG, bench.CFG_EXP):
         ref_loss, ref_grads = bench.oracle_fp64_on_gpu(cfg, feats)
-        try:
-            for mode in (0, 2):
-                ops.set_gemm_mode(mode)
-                xs = [f.detach().clone().requires_grad_(True) for f in feats]
-                track = OrderedDict()
+        for mode in (0, 2):
+            xs = [f.detach().clone().requires_grad_(True) for f in feats]
+            track = OrderedDict()
+            with ops.gemm_mode(mode):    # the autograd node keeps the mode for its backward (which runs on another thread)
                 out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, track)
-                out.backward()
-                assert len(track['layer_track']) == 5
-                rec = bench.parity_record(float(out.item()), [x.grad for x in xs], ref_loss, ref_grads)
-                assert rec['loss_rel'] <= RTOL, (mode, rec)
-                assert rec['grad_rel_max'] <= RTOL, (mode, rec)
-                del xs, out, track
-        finally:
-            ops.set_gemm_mode(0)
+            out.backward()
+            assert len(track['layer_track']) == 5
+            rec = bench.parity_record(float(out.item()), [x.grad for x in xs], ref_loss, ref_grads)
+            assert rec['loss_rel'] <= RTOL, (mode, rec)
+            assert rec['grad_rel_max'] <= RTOL, (mode, rec)
+            del xs, out, track
         del ref_grads
         torch.cuda.empty_cache()
 

@@ -17,7 +17,7 @@ for name, W, X in (('mixed signs', torch.randn(M, B, B, device=dev), torch.randn
     wmax = W.abs().amax(dim=(1, 2)).contiguous()
     xmax = X.abs().amax(dim=(1, 2)).contiguous()
     dX = torch.empty_like(X)
-    assert L.hecka_gram_bwd_f32(W.data_ptr(), X.data_ptr(), wmax.data_ptr(), xmax.data_ptr(), None, M, B, P, dX.data_ptr(), st) == 0
+    assert L.hecka_gram_bwd_f32(W.data_ptr(), X.data_ptr(), wmax.data_ptr(), xmax.data_ptr(), None, M, B, P, dX.data_ptr(), 0, st) == 0
     ref = torch.bmm(W.double(), X.double())
     sabs = torch.bmm(W.double().abs(), X.double().abs())
     e = (dX.double() - ref) / sabs

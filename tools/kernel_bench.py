@@ -17,7 +17,7 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 X = torch.randn(M, B, P, device=dev)
 L = _lib.lib()
-L.hecka_set_gemm_mode(int(os.environ.get('HECKA_GEMM_MODE', '0')))
+MODE = int(os.environ.get('HECKA_GEMM_MODE', '0'))
 st = torch.cuda.current_stream().cuda_stream
 p = lambda t: t.data_ptr()
 sbar = torch.empty(M, P, device=dev)
@@ -30,18 +30,18 @@ gamma = torch.randn(M, B, device=dev)
 xmax = torch.empty(M, device=dev)
 wmax = torch.empty(M, device=dev)
 L.hecka_colmean_f32(p(X), M, B, P, p(sbar), p(xmax), st)
-L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), st)
+L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), MODE, st)
 nb = L.hecka_pairwise_workspace_bytes(M, M, B * B)
 ws = torch.empty(max(nb, 4) // 4, device=dev)
 S = torch.empty(M, M, device=dev)
 fns = {
     'colmean': (lambda: L.hecka_colmean_f32(p(X), M, B, P, p(sbar), p(xmax), st), 0, 4.0 * M * B * P),
-    'gram_center': (lambda: L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), st), 2.0 * M * B * B * P, 0),
+    'gram_center': (lambda: L.hecka_gram_center_f32(p(X), p(sbar), p(xmax), M, B, P, p(C), p(cvec), MODE, st), 2.0 * M * B * B * P, 0),
     'pairwise': (lambda: L.hecka_pairwise_f32(p(C), M, p(C), M, B * B, p(S), p(ws), nb, st), 2.0 * M * M * B * B, 4.0 * M * B * B),
     'combine': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st), 2.0 * M * M * B * B, 8.0 * M * B * B),
     'combine_nomax': (lambda: L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), None, st), 2.0 * M * M * B * B, 8.0 * M * B * B),
     'head_fwd': (lambda: L.hecka_head_fwd_f32(p(S), p(nsq), M, M, 0, 1, 2.0, 0.0025, 0.031, 4, None, p(tot), 1.0, st), 0, 0),
-    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), p(wmax), p(xmax), None, M, B, P, p(dX), st), 2.0 * M * B * B * P, 0),
+    'gram_bwd': (lambda: L.hecka_gram_bwd_f32(p(W), p(X), p(wmax), p(xmax), None, M, B, P, p(dX), MODE, st), 2.0 * M * B * B * P, 0),
 }
 L.hecka_combine_f32(p(A), p(C), p(gamma), M, M, B, 1, p(W), p(wmax), st)   # W and wmax consistent for gram_bwd
 L.hecka_pairwise_f32(p(C), M, p(C), M, B * B, p(S), p(ws), nb, st)
