@@ -2183,13 +2183,157 @@ __global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const float* __restr
   y[c] = a;
 }
 
+// ------------------------------------------------------------------------------------------
+// Hypernetwork sampler side: the shared-weight GroupNorm-MLPs that turn latent codes into the members'
+// parameters (hyper/net/models.py:60-188, hyper/net/spectral.py).  Rows = sampled members (128), so these are skinny
+// problems over LARGE shared weight matrices (the MNIST hypernetwork's output layer is 30840 x 2294): HBM-bound.
+// ------------------------------------------------------------------------------------------
+// y[h] = W[h,:] . v   (W row-major [H, Wd]): one wave per row, lanes stride the row in 16-byte pieces; fixed-order
+// (butterfly) reduction: deterministic.  The power-iteration step u <- normalize(W v) and sigma = u . (W v).
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ Wm, const float* __restrict__ v,
+                                                   float* __restrict__ y, int H, int Wd, int vec) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= H) return;
+  const float* w = Wm + (size_t)row * Wd;
+  float a = 0.f;
+  if (vec) {
+    for (int c = lane * 4; c < Wd; c += 256) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(w + c), x = *reinterpret_cast<const f32x4*>(v + c);
+      a = fmaf(q[0], x[0], a); a = fmaf(q[1], x[1], a); a = fmaf(q[2], x[2], a); a = fmaf(q[3], x[3], a);
+    }
+  } else {
+    for (int c = lane; c < Wd; c += 64) a = fmaf(w[c], v[c], a);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) y[row] = a;
+}
+
+// out[h,w] = alpha[0] * u[h] * v[w]: gradient of sigma = u . (W v) with respect to W (u, v constants), alpha = dLoss/dsigma
+__global__ __launch_bounds__(256) void ger_kernel(const float* __restrict__ alpha, const float* __restrict__ u,
+                                                  const float* __restrict__ v, float* __restrict__ out, int H, int Wd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Wd) return;
+  const float a = alpha[0] * v[c];
+  const int r0 = blockIdx.y * 64, r1 = min(H, r0 + 64);
+  for (int r = r0; r < r1; ++r) out[(size_t)r * Wd + c] = a * u[r];
+}
+
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float z) {
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// GroupNorm over the channels of a [N, C] matrix (nn.GroupNorm on 2-D input: statistics per (row, group) over C / G
+// channels, biased variance) with the GELU that follows it in a norm block fused in.  One workgroup per (group, row);
+// two-pass variance.  act: 0 none, 1 GELU (erf form, nn.GELU()).  mean / rstd [N, G] are kept for backward.
+__global__ __launch_bounds__(256) void groupnorm_fwd_kernel(const float* __restrict__ x, int C, int G, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, int act,
+                                                            float* __restrict__ y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, n = blockIdx.y, cg = C / G, c0 = g * cg;
+  const float* xr = x + (size_t)n * C + c0;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cg; c += 256) s += xr[c];
+  const float mu = block_sum256(s, red) / (float)cg;
+  float q = 0.f;
+  for (int c = threadIdx.x; c < cg; c += 256) { const float d = xr[c] - mu; q = fmaf(d, d, q); }
+  const float rs = rsqrtf(block_sum256(q, red) / (float)cg + eps);
+  if (threadIdx.x == 0) { mean[(size_t)n * G + g] = mu; rstd[(size_t)n * G + g] = rs; }
+  float* yr = y + (size_t)n * C + c0;
+  for (int c = threadIdx.x; c < cg; c += 256) {
+    float z = (xr[c] - mu) * rs;
+    if (w) z = fmaf(z, w[c0 + c], b ? b[c0 + c] : 0.f);
+    yr[c] = act == 1 ? gelu_f(z) : z;
+  }
+}
+
+// dx for the same block; dzx [N, C] (may be NULL when no affine gradient is wanted) receives dz = dy * act'(z), the
+// gradient at the affine output, for the channel-wise reduction below.
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int C, int G,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int act, float* __restrict__ dx) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, n = blockIdx.y, cg = C / G, c0 = g * cg;
+  const float mu = mean[(size_t)n * G + g], rs = rstd[(size_t)n * G + g];
+  const float* xr = x + (size_t)n * C + c0;
+  const float* dr = dy + (size_t)n * C + c0;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = threadIdx.x; c < cg; c += 256) {
+    const float xh = (xr[c] - mu) * rs, wc = w ? w[c0 + c] : 1.f;
+    float dz = dr[c];
+    if (act == 1) dz *= gelu_df(fmaf(xh, wc, (w && b) ? b[c0 + c] : 0.f));
+    const float dh = dz * wc;
+    s1 += dh;
+    s2 = fmaf(dh, xh, s2);
+  }
+  const float m1 = block_sum256(s1, red) / (float)cg;
+  const float m2 = block_sum256(s2, red) / (float)cg;
+  float* dxr = dx + (size_t)n * C + c0;
+  for (int c = threadIdx.x; c < cg; c += 256) {
+    const float xh = (xr[c] - mu) * rs, wc = w ? w[c0 + c] : 1.f;
+    float dz = dr[c];
+    if (act == 1) dz *= gelu_df(fmaf(xh, wc, (w && b) ? b[c0 + c] : 0.f));
+    dxr[c] = rs * (dz * wc - m1 - xh * m2);
+  }
+}
+
+// dweight[c] = sum_n dz[n,c] xhat[n,c], dbias[c] = sum_n dz[n,c]: one thread per channel walks the rows in order
+// (deterministic; N is the member count, 128)
+__global__ __launch_bounds__(256) void groupnorm_affine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int N,
+                                                                   int C, int G, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, int act,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+  // 16 channels x 16 row lanes per workgroup: each lane strides over the rows, the 16 partial sums of a channel meet in
+  // LDS and are added in lane order (deterministic)
+  __shared__ float saw[16][17], sab[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float aw = 0.f, ab = 0.f;
+  if (c < C) {
+    const int g = c / (C / G);
+    const float wc = w[c], bc = b ? b[c] : 0.f;
+    for (int n = rl; n < N; n += 16) {
+      const float xh = (x[(size_t)n * C + c] - mean[(size_t)n * G + g]) * rstd[(size_t)n * G + g];
+      float dz = dy[(size_t)n * C + c];
+      if (act == 1) dz *= gelu_df(fmaf(xh, wc, bc));
+      aw = fmaf(dz, xh, aw);
+      ab += dz;
+    }
+  }
+  saw[cl][rl] = aw;
+  sab[cl][rl] = ab;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float tw = 0.f, tb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      tw += saw[cl][r];
+      tb += sab[cl][r];
+    }
+    dw[c] = tw;
+    if (db) db[c] = tb;
+  }
+}
+
 }  // namespace hecka
 
 using namespace hecka;
 
 extern "C" {
 
-int hecka_version(void) { return 5; }
+int hecka_version(void) { return 6; }
 
 static inline bool gemm_mode_ok(int mode) {
   return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
@@ -3209,6 +3353,50 @@ int hecka_gemv_t_f32(const float* Wm, const float* u, int H, int Wd, float* y, v
   hipLaunchKernelGGL(gemv_t_kernel, dim3(colblocks, S), dim3(256), 0, st, Wm, u, static_cast<float*>(ws), H, Wd, rper);
   hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3(colblocks), dim3(256), 0, st, static_cast<const float*>(ws), y, S, Wd);
   return check_launch("gemv_t");
+}
+
+int hecka_gemv_f32(const float* Wm, const float* v, int H, int Wd, float* y, void* stream) {
+  clear_error();
+  if (!Wm || !v || !y) return fail(HECKA_EINVAL, "gemv: null pointer%s");
+  if (H <= 0 || Wd <= 0) return fail(HECKA_EINVAL, "gemv: non-positive size%s");
+  const int vec = (Wd % 4 == 0) && aligned16(Wm) && aligned16(v);
+  hipLaunchKernelGGL(gemv_kernel, dim3((H + 3) / 4), dim3(256), 0, (hipStream_t)stream, Wm, v, y, H, Wd, vec);
+  return check_launch("gemv");
+}
+
+int hecka_ger_f32(const float* alpha, const float* u, const float* v, int H, int Wd, float* out, void* stream) {
+  clear_error();
+  if (!alpha || !u || !v || !out) return fail(HECKA_EINVAL, "ger: null pointer%s");
+  if (H <= 0 || Wd <= 0 || (H + 63) / 64 > 65535) return fail(HECKA_EINVAL, "ger: size out of range%s");
+  hipLaunchKernelGGL(ger_kernel, dim3((Wd + 255) / 256, (H + 63) / 64), dim3(256), 0, (hipStream_t)stream, alpha, u, v, out, H, Wd);
+  return check_launch("ger");
+}
+
+int hecka_groupnorm_fwd_f32(const float* x, int N, int C, int G, const float* weight, const float* bias, float eps, int act,
+                            float* y, float* mean, float* rstd, void* stream) {
+  clear_error();
+  if (!x || !y || !mean || !rstd) return fail(HECKA_EINVAL, "groupnorm_fwd: null pointer%s");
+  if (N <= 0 || C <= 0 || G <= 0 || C % G != 0 || N > 65535) return fail(HECKA_EINVAL, "groupnorm_fwd: needs C %% G == 0, N <= 65535%s");
+  if (act != 0 && act != 1) return fail(HECKA_EINVAL, "groupnorm_fwd: act must be 0 (none) or 1 (gelu)%s");
+  if (bias && !weight) return fail(HECKA_EINVAL, "groupnorm_fwd: bias without weight%s");
+  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, C, G, weight, bias, eps, act, y, mean, rstd);
+  return check_launch("groupnorm_fwd");
+}
+
+int hecka_groupnorm_bwd_f32(const float* dy, const float* x, int N, int C, int G, const float* weight, const float* bias,
+                            const float* mean, const float* rstd, int act, float* dx, float* dweight, float* dbias,
+                            void* stream) {
+  clear_error();
+  if (!dy || !x || !mean || !rstd) return fail(HECKA_EINVAL, "groupnorm_bwd: null pointer%s");
+  if (N <= 0 || C <= 0 || G <= 0 || C % G != 0 || N > 65535) return fail(HECKA_EINVAL, "groupnorm_bwd: needs C %% G == 0, N <= 65535%s");
+  if (act != 0 && act != 1) return fail(HECKA_EINVAL, "groupnorm_bwd: act must be 0 (none) or 1 (gelu)%s");
+  if ((dweight || dbias) && !weight) return fail(HECKA_EINVAL, "groupnorm_bwd: affine gradients without weight%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(G, N), dim3(256), 0, st, dy, x, C, G, weight, bias, mean, rstd, act, dx);
+  if (dweight)
+    hipLaunchKernelGGL(groupnorm_affine_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, st, dy, x, N, C, G, weight, bias, mean, rstd,
+                       act, dweight, dbias);
+  return check_launch("groupnorm_bwd");
 }
 
 int hecka_crater_f32(const float* x, const float* dy, float* out, long long n, void* stream) {

@@ -56,6 +56,10 @@ SIGNATURES = {
     'hecka_conv_direct_wgrad_f32': (_i, [_vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_gemv_t_workspace_bytes': (_sz, [_i, _i]),
     'hecka_gemv_t_f32': (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    'hecka_gemv_f32': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'hecka_ger_f32': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'hecka_groupnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp]),
+    'hecka_groupnorm_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'hecka_crater_f32': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'hecka_crater_maxpool2_f32': (_i, [_vp, _vp, _vp, _ll, _i, _i, _vp]),
     'hecka_batchnorm_act_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

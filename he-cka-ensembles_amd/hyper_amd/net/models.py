@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.init as init
 
+from . import hip
 from .activation import activation_gamma
 from .spectral import SpectralLinear
 
@@ -34,7 +35,7 @@ def build_norm_block(in_features, out_features, bias, act, norm, gamma, norm_gro
         linear = SpectralLinear(in_features, out_features, bias=bias, coeff=coeff, n_power_iterations=1)
         weight = linear.weight_orig
     else:
-        linear = nn.Linear(in_features, out_features, bias=bias)
+        linear = hip.Linear(in_features, out_features, bias=bias)      # nn.Linear, GPU work in libhecka
         weight = linear.weight
     with torch.no_grad():
         invsq = math.sqrt(1.0 / in_features)
@@ -46,10 +47,11 @@ def build_norm_block(in_features, out_features, bias, act, norm, gamma, norm_gro
         std = weight.std(dim=1, keepdim=True, unbiased=False)
         weight.sub_(mean).mul_((invsq * activation_gamma(gamma)) / (std + eps))
     parts = [('linear', linear)]
+    fuse = norm and act is nn.GELU      # GroupNorm -> GELU in one kernel (hecka_groupnorm_*_f32); `act` has no state
     if norm:
         groups = calculate_mlp_groupnorm_groups(out_features) if norm_groups is None else norm_groups
-        parts.append(('norm', nn.GroupNorm(num_groups=groups, num_channels=out_features, affine=affine)))
-    if act is not None:
+        parts.append(('norm', hip.GroupNorm(num_groups=groups, num_channels=out_features, affine=affine, fused_gelu=fuse)))
+    if act is not None and not fuse:
         parts.append(('act', act()))
     return nn.Sequential(OrderedDict(parts))
 
@@ -77,8 +79,8 @@ def build_groupnorm_mlp(in_features, out_features, mlp_dims=3, dim_multiplier=2,
                                                      act=activation, norm=(ind % norm_every == 0), coeff=coeff)
     assert not (norm_before_last and norm_last), 'Double norming please only set one to true'
     if norm_before_last:
-        layers['group_norm'] = nn.GroupNorm(num_groups=calculate_mlp_groupnorm_groups(dims[-1]), num_channels=dims[-1],
-                                            affine=True)
+        layers['group_norm'] = hip.GroupNorm(num_groups=calculate_mlp_groupnorm_groups(dims[-1]), num_channels=dims[-1],
+                                             affine=True)
     layers['output'] = build_norm_block(dims[-1], out_features, bias=bias, act=out_act, gamma=activation, norm=norm_last,
                                         affine=affine_last, norm_groups=1, coeff=coeff)
     return nn.Sequential(layers)

@@ -5,27 +5,14 @@ graph (u, v constants), as in the reference.
 
 The reference wraps an nn.Linear with a forward-pre hook; here it is one module with the same state-dict keys
 (`weight_orig`, `bias`, `weight_u`, `weight_v`, `weight_sigma`), so checkpoints move both ways.  The power
-iteration + sigma are torch ops on the current stream (two matrix-vector products per layer: small against the
-ensemble forward; they replay inside a captured step like everything else)."""
+iteration + sigma run on the current stream (hyper_amd.net.hip: W v, W^T u and the layer's own product in libhecka;
+they replay inside a captured step like everything else)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
-def _mv_t(W, u):
-    """W^T u.  Large fp32 GPU matrices take hecka_gemv_t_f32 (rocBLAS reads the 30840 x 2294 output layer of the MNIST
-    hypernetwork at 0.4 TB/s for this product); everything else torch.mv."""
-    if W.is_cuda and W.dtype == torch.float32 and W.is_contiguous() and W.numel() >= (1 << 18) and u.is_contiguous():
-        from .. import _lib
-        L = _lib.lib()
-        H, Wd = W.shape
-        nbytes = L.hecka_gemv_t_workspace_bytes(H, Wd)
-        ws = torch.empty((nbytes // 4,), device=W.device, dtype=torch.float32)
-        y = torch.empty((Wd,), device=W.device, dtype=torch.float32)
-        _lib.check(L.hecka_gemv_t_f32(W.data_ptr(), u.data_ptr(), H, Wd, y.data_ptr(), ws.data_ptr(), nbytes,
-                                      torch.cuda.current_stream(W.device).cuda_stream), 'gemv_t')
-        return y
-    return torch.mv(W.t(), u)
+from . import hip
 
 
 class SpectralLinear(nn.Module):
@@ -53,10 +40,10 @@ class SpectralLinear(nn.Module):
         if do_power_iteration:
             with torch.no_grad():
                 for _ in range(self.n_power_iterations):
-                    F.normalize(_mv_t(W.detach(), u), dim=0, eps=self.eps, out=v)
-                    F.normalize(torch.mv(W, v), dim=0, eps=self.eps, out=u)
+                    F.normalize(hip.matvec_t(W.detach(), u), dim=0, eps=self.eps, out=v)
+                    F.normalize(hip.matvec(W.detach(), v), dim=0, eps=self.eps, out=u)
                 u, v = u.clone(), v.clone()   # the buffers change again next forward; the graph keeps these
-        sigma = torch.dot(u, torch.mv(W, v))
+        sigma = (u * hip.matvec(W, v)).sum()      # u . (W v) without a BLAS call
         with torch.no_grad():
             self.weight_sigma.copy_(sigma.detach().reshape(1))
         # soft normalisation: only when sigma exceeds coeff.  Written as the reference writes it (a float32 ones(1)
@@ -70,7 +57,7 @@ class SpectralLinear(nn.Module):
     def forward(self, x):
         # linear(x, W / f, b) = linear(x, W) / f + b: the scalar goes on the [members, out] result instead of a pass over
         # the weight matrix forward and two backward (the MNIST hypernetwork's output layer is 30840 x 2294)
-        y = F.linear(x, self.weight_orig) / self._sigma(self.training)
+        y = hip.linear(x, self.weight_orig) / self._sigma(self.training)
         return y if self.bias is None else y + self.bias
 
     def extra_repr(self):

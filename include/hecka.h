@@ -311,6 +311,26 @@ int hecka_conv_direct_wgrad_f32(const float* x, long long x_member_stride, const
 size_t hecka_gemv_t_workspace_bytes(int H, int Wd);
 int hecka_gemv_t_f32(const float* W, const float* u, int H, int Wd, float* y, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- hypernetwork sampler side: shared-weight GroupNorm-MLPs over the sampled members ---------------
+ * The Linear layers of those MLPs (hyper/net/models.py:60-127 `build_norm_block`: nn.Linear / spectral_norm_fc) are
+ * hecka_bgemm_f32 calls with batch = 1 (forward nn = 0 with the bias epilogue, dgrad nn = 1, wgrad on transposed operands).
+ * hecka_gemv_f32: y [H] = W v for a row-major W [H, Wd] - the power-iteration step u <- normalize(W v) and
+ *   sigma = u . (W v) of the soft spectral normalisation (hyper/net/spectral.py:92-99 `torch.mv(weight_mat, v)`); one wave
+ *   per row, deterministic.  (W^T u is hecka_gemv_t_f32 below.)
+ * hecka_ger_f32: out [H, Wd] = alpha[0] u v^T - autograd's gradient of sigma with respect to the weight (u, v constants),
+ *   alpha = device scalar dLoss/dsigma.
+ * hecka_groupnorm_*: nn.GroupNorm on [N, C] rows (hyper/net/models.py:99-101, gpnorm.py:9-31; statistics per (row, group),
+ *   biased variance) with the nn.GELU() that follows it in a norm block fused in (act = 1; 0 = none): forward keeps
+ *   mean / rstd [N, G]; backward recomputes the activation's argument from x.  weight / bias [C] may be NULL (affine off);
+ *   dx / dweight / dbias may be NULL. */
+int hecka_gemv_f32(const float* W, const float* v, int H, int Wd, float* y, void* stream);
+int hecka_ger_f32(const float* alpha, const float* u, const float* v, int H, int Wd, float* out, void* stream);
+int hecka_groupnorm_fwd_f32(const float* x, int N, int C, int G, const float* weight, const float* bias, float eps, int act,
+                            float* y, float* mean, float* rstd, void* stream);
+int hecka_groupnorm_bwd_f32(const float* dy, const float* x, int N, int C, int G, const float* weight, const float* bias,
+                            const float* mean, const float* rstd, int act, float* dx, float* dweight, float* dbias,
+                            void* stream);
+
 /* crater activation y = c x (1 + tanh((x + 1) / sqrt 2)) of the target nets (hyper/net/activation.py:8-12; the reference
  * composes it from five elementwise torch ops, each a pass over the tensor).  dy == NULL: out = crater(x); otherwise
  * out = dy * crater'(x).  n elements, 16-byte aligned. */

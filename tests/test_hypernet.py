@@ -6,6 +6,7 @@ CPU part (here): the generators are shared-weight torch modules, so parameter ge
 GPU - state-dict keys, generated LeNet parameters, power-iteration buffers after the forward, RNG-order of the
 initialisation.  GPU part (marked gpu): the whole step - generated parameters through the batched LeNet on libhecka,
 RepulsiveKernel with inlier + outlier HE terms, backward into the hypernetwork."""
+import copy
 import json
 import os
 import sys
@@ -138,17 +139,82 @@ def test_hypernetwork_train_step_matches_reference(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,Wd', [(30840, 2294), (513, 517), (700, 3), (64, 4096)])
-def test_gemv_t_matches_fp64(H, Wd):
-    """hecka_gemv_t_f32 (power-iteration product W^T u) against the fp64 product."""
-    from hyper_amd.net.spectral import _mv_t
+def test_power_iteration_products_match_fp64(H, Wd):
+    """hecka_gemv_t_f32 (W^T u), hecka_gemv_f32 (W v) and the rank-one gradient of u.(W v) (hecka_ger_f32) against fp64."""
+    from hyper_amd.net import hip
     dev = torch.device('cuda:0')
     torch.manual_seed(2)
-    W = torch.randn(H, Wd, device=dev)
+    W = torch.randn(H, Wd, device=dev, requires_grad=True)
     u = torch.randn(H, device=dev)
-    y = _mv_t(W, u)
-    ref = torch.mv(W.double().t(), u.double())
+    v = torch.randn(Wd, device=dev)
+    y = hip.matvec_t(W.detach(), u)
+    ref = torch.mv(W.detach().double().t(), u.double())
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max() / ref.abs().max()) <= 2e-6
+    z = hip.matvec(W, v)
+    refz = torch.mv(W.detach().double(), v.double())
+    assert z.shape == refz.shape
+    assert float((z.detach().double() - refz).abs().max() / refz.abs().max()) <= 2e-6
+    sigma = torch.dot(u, z)
+    (3.0 * sigma).backward()
+    refg = 3.0 * torch.outer(u.double(), v.double())
+    assert float((W.grad.double() - refg).abs().max() / refg.abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,G,gelu,affine', [(4, 64, 8, True, True), (6, 512, 32, True, True), (3, 30840, 8, False, True),
+                                               (17, 100, 5, True, False), (2, 48, 6, False, True), (5, 96, 1, True, True)])
+def test_groupnorm_gelu_kernel_matches_torch_fp64(N, C, G, gelu, affine):
+    """hecka_groupnorm_{fwd,bwd}_f32 (GroupNorm + fused GELU of the generator's norm blocks, hyper/net/models.py:60-118)
+    against torch's F.group_norm / F.gelu in float64: output, dx, dweight, dbias within 1e-5 of the largest entry."""
+    import torch.nn.functional as F
+    from hyper_amd.net import hip
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 1000 + C)
+    x = (torch.randn(N, C, device=dev) * 2.0 + 0.3).requires_grad_(True)
+    w = (torch.randn(C, device=dev) * 0.5 + 1.0).requires_grad_(True) if affine else None
+    b = (torch.randn(C, device=dev) * 0.2).requires_grad_(True) if affine else None
+    dy = torch.randn(N, C, device=dev)
+    y = hip.group_norm(x, G, w, b, 1e-5, gelu=gelu)
+    assert y.grad_fn is not None and 'GroupNormAct' in type(y.grad_fn).__name__
+    y.backward(dy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True) if affine else None
+    bd = b.detach().double().requires_grad_(True) if affine else None
+    yd = F.group_norm(xd, G, wd, bd, 1e-5)
+    if gelu:
+        yd = F.gelu(yd)
+    yd.backward(dy.double())
+    pairs = [('y', y.detach(), yd.detach()), ('dx', x.grad, xd.grad)]
+    if affine:
+        pairs += [('dweight', w.grad, wd.grad), ('dbias', b.grad, bd.grad)]
+    for name, got, ref in pairs:
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-5, (name, err)
+
+
+@pytest.mark.gpu
+def test_generator_mlp_runs_on_libhecka_kernels():
+    """The generator's norm blocks on the GPU: Linear through the grouped GEMM (BatchedLinear node), GroupNorm + GELU
+    through the fused kernel, same state-dict keys as the reference's Sequential(linear, norm[, act])."""
+    from hyper_amd.net import hip
+    from hyper_amd.net.models import build_norm_block
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    blk = build_norm_block(24, 64, bias=True, act=torch.nn.GELU, norm=True, gamma=None).to(dev)
+    assert sorted(blk.state_dict()) == ['linear.bias', 'linear.weight', 'norm.bias', 'norm.weight']
+    assert isinstance(blk.linear, hip.Linear) and isinstance(blk.norm, hip.GroupNorm) and blk.norm.fused_gelu
+    x = torch.randn(7, 24, device=dev, requires_grad=True)
+    y = blk(x)
+    y.square().sum().backward()
+    ref = copy.deepcopy(blk).double().cpu()
+    xd = x.detach().double().cpu().requires_grad_(True)
+    yd = ref(xd)
+    yd.square().sum().backward()
+    assert float((y.detach().cpu().double() - yd.detach()).abs().max()) <= 1e-5 * float(yd.detach().abs().max())
+    assert float((x.grad.cpu().double() - xd.grad).abs().max()) <= 2e-5 * float(xd.grad.abs().max())
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-5 * float(q.grad.abs().max()), n
 
 
 @pytest.mark.gpu
