@@ -123,8 +123,12 @@ struct implicit_nt : std::false_type {};
 template <class P>
 struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constant<P::kImplicitNT> {};
 
-// Product tile out[i,j] = sum_k A[i,k] B(k,j), interior tiles only (rows/cols multiples of the tile, (kend - kbeg) a
-// multiple of 16, 16-byte aligned A rows).  A is [rows, K] (k contiguous).  NN = false: B is [cols, K] (k contiguous,
+// Product tile out[i,j] = sum_k A[i,k] B(k,j).  RAGGED = false: interior tiles only (rows/cols multiples of the tile,
+// (kend - kbeg) a multiple of 16, 16-byte aligned A rows).  RAGGED = true: any row / column count and any k range that is
+// a multiple of 4 for the k-contiguous operands (whole quads; row starts stay 16-byte aligned) - the whole address of a
+// load sits in the bounds-checked VGPR offset, so rows past the operand's end read as zero, quads past kend are sent
+// out of range on purpose, and the caller masks the rows / columns of the result that do not exist.  Operands below
+// 2 GiB.  (The reference's own batch sizes - 300, 100, 400 - are ragged.)  A is [rows, K] (k contiguous).  NN = false: B is [cols, K] (k contiguous,
 // 16-byte aligned rows); NN = true: B is [K, cols] (cols contiguous) and is transposed on the way into LDS - a thread
 // gathers 8 k of ONE column with dword loads (a wave-load = 256 contiguous bytes of one k-row).
 // Pro: transform of the staged fp32 values (centring), NT only.
@@ -134,8 +138,10 @@ struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constan
 // term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
 // ALOW = false: the same for A (both false: one product, hh).
 template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
-          bool BLOW = true, bool ALOW = true, bool SAMEAB = false>
+          bool BLOW = true, bool ALOW = true, bool SAMEAB = false, bool RAGGED = false>
 struct GemmTileX6 {
+  static_assert(!RAGGED || (!implicit_b<Pro>::value && !implicit_nt<Pro>::value), "ragged tiles: explicit operands only");
+  static constexpr unsigned kOOB = 0x80000000u;   // a byte offset no (< 2 GiB) operand reaches: the load returns zero
   // SAMEAB (NT, diagonal tile of a symmetric product): the B rows ARE the A rows - nothing is loaded, split or staged
   // for B, its fragments come from the A planes
   static_assert(!SAMEAB || (!NN && TM == TN), "SAMEAB: NT product with a square tile");
@@ -177,7 +183,8 @@ struct GemmTileX6 {
     for (int i = 0; i < CB; ++i)
       bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) *
                  (unsigned)SB;
-    const int ntiles = (kend - kbeg) / kX6BK;
+    const int klen = kend - kbeg;
+    const int ntiles = RAGGED ? (klen + kX6BK - 1) / kX6BK : klen / kX6BK;
     if (ntiles <= 0) return;
     auto& smb = *[&]() {      // the planes the B fragments are read from
       if constexpr (SAMEAB) return &sm.a;
@@ -191,12 +198,14 @@ struct GemmTileX6 {
       if constexpr (implicit_nt<Pro>::value) pro.seek(kt);
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
+        const unsigned vo = RAGGED ? (kt * kX6BK + 4 * kq < klen ? aoff[i] + so : kOOB) : aoff[i];
+        const unsigned so_ = RAGGED ? 0u : so;
         if constexpr (implicit_nt<Pro>::value) {
           ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)pro.avoff(i), 0, 0));
         } else if (EA == kElemF32) {
-          ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[i], (int)so, 0));
+          ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)vo, (int)so_, 0));
         } else {
-          const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)aoff[i], (int)so, 0);
+          const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)vo, (int)so_, 0);
           ra[S][i][0] = __uint_as_float(r[0]);
           ra[S][i][1] = __uint_as_float(r[1]);
         }
@@ -216,22 +225,32 @@ struct GemmTileX6 {
               rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)pro.bvoff(k), 0, 0));
               continue;
             }
-            const int so = (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * (unsigned)SB);
+            int so = (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * (unsigned)SB);
+            unsigned vo = bgoff[i];
+            if (RAGGED) {
+              vo = kt * kX6BK + 8 * (t >> 7) + 4 * i + c < klen ? bgoff[i] + (unsigned)so : kOOB;
+              so = 0;
+            }
             if (EB == kElemF32)
-              rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)bgoff[i], so, 0));
+              rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)vo, so, 0));
             else
-              rb[S][i][c] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsB, (int)bgoff[i], so, 0));
+              rb[S][i][c] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsB, (int)vo, so, 0));
           }
         } else if constexpr (implicit_nt<Pro>::value) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)pro.btoff(i, c), 0, 0));
         } else {
-          const int so = (int)(sB0 + (unsigned)kt * (unsigned)(kX6BK * SB));
+          int so = (int)(sB0 + (unsigned)kt * (unsigned)(kX6BK * SB));
+          unsigned vo = bgoff[i];
+          if (RAGGED) {
+            vo = kt * kX6BK + 4 * kq < klen ? bgoff[i] + (unsigned)so : kOOB;
+            so = 0;
+          }
           if (EB == kElemF32) {
-            rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[i], so, 0));
+            rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)vo, so, 0));
           } else {
-            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)bgoff[i], so, 0);
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsB, (int)vo, so, 0);
             rb[S][i][0] = __uint_as_float(r[0]);
             rb[S][i][1] = __uint_as_float(r[1]);
           }

@@ -282,14 +282,16 @@ __device__ __forceinline__ void tri_tile(int rem, int ntile, int& I, int& J) {
 #define HECKA_DIAG_TILES 1
 #endif
 
-template <int SCHEME>
+template <int SCHEME, bool RAGGED = false>
 struct CenterProX6 {
   const float* sbar;
+  int klim;               // RAGGED: features of the layer (quads at k >= klim are padding: mean 0 like the zero-filled x)
   float s;                // operand scale (SCHEME 1), 1 otherwise
   f32x4 s4[2];            // means of the k-quad this thread stages, per register set
   f32x4 cav[2], cbv[2];   // per-lane partial dots sbar . (x - sbar), one accumulator per staged element
   template <class S> __device__ __forceinline__ void prefetch(S, int k) {
-    s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
+    if (RAGGED && k >= klim) s4[S::value] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
   }
   template <class S> __device__ __forceinline__ void stage(S, f32x4& v, f32x4& acc) {
     const f32x4 m4 = s4[S::value];
@@ -398,13 +400,14 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   });
 }
 
-template <int SCHEME, int EX = kElemF32>
+template <int SCHEME, int EX = kElemF32, bool RAGGED = false>
 __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
                                                     int w, int kbeg, int kend) {
-  using Tile = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX>;
-  using TileD = GemmTileX6<128, 128, false, CenterProX6<SCHEME>, SCHEME, true, EX, EX, true, true, true>;   // diagonal tiles
+  using Pro = CenterProX6<SCHEME, RAGGED>;
+  using Tile = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, false, RAGGED>;
+  using TileD = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, true, RAGGED>;   // diagonal tiles
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
@@ -413,7 +416,8 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   int I, J;
   tri_tile(rem, ntile, I, J);
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * ES;
-  CenterProX6<SCHEME> pro;
+  Pro pro;
+  pro.klim = P;
   pro.sbar = sbar + (size_t)m * P;
   pro.s = SCHEME == 1 ? pow2_scale(xmax[m], 13) : 1.0f;
   pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -446,21 +450,23 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   __syncthreads();
   float* Cm = C + (size_t)m * B * B;
   const int row0 = I * 128, col0 = J * 128;
-  if (I == J && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
+  if (I == J && threadIdx.x < 128 && (!RAGGED || row0 + (int)threadIdx.x < B))
+    cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
   tile.for_each([&](int lr, int lc, float v) {
+    if (RAGGED && (row0 + lr >= B || col0 + lc >= B)) return;     // rows / columns of the padded tile that do not exist
     if (SCHEME == 1) v *= unscale;
     Cm[(size_t)(row0 + lr) * B + col0 + lc] = v + cB[lc];
     if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v + cA[lr];
   });
 }
 
-template <int SCHEME>
+template <int SCHEME, bool RAGGED = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
                                                                      const float* __restrict__ sbar,
                                                                      const float* __restrict__ xmax,
                                                                      float* __restrict__ C, float* __restrict__ cvec,
                                                                      int B, int P, int ntile, int xcd_map) {
-  gram_center_x6_body<SCHEME>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, (int)blockIdx.x, 0, P);
+  gram_center_x6_body<SCHEME, kElemF32, RAGGED>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, (int)blockIdx.x, 0, P);
 }
 
 // All tracked layers in ONE launch.  A layer's Gram is M * 10 equal workgroups (B = 512) on 512 resident slots: launched
@@ -509,8 +515,9 @@ __global__ __launch_bounds__(256) void gram_split_reduce_kernel(GramMultiArgs a,
   }
 }
 
-template <int SCHEME, int EX = kElemF32, bool RAW = false>
+template <int SCHEME, int EX = kElemF32, bool RAW = false, bool RAGGED = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
+  static_assert(!(RAW && RAGGED), "the raw 16-bit Gram is written for interior shapes");
   const int w = blockIdx.x;
   int li = 0, w0 = 0;
   while (li + 1 < a.L && w >= a.l[li].wg_end) {
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
     cvec = cws + (size_t)z * a.M * B;
   }
   if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
-  else gram_center_x6_body<SCHEME, EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
+  else gram_center_x6_body<SCHEME, EX, RAGGED>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -952,14 +959,14 @@ struct ScaleProX6 {
 // TM = 256 (no local chains only): each wave owns 128 x 64 of a 256 x 128 tile - a staged X tile feeds twice the MFMAs
 // (24 per k-tile per wave behind one barrier), fragment reads and staging work per MFMA fall by a quarter; two
 // workgroups per CU (128 accumulator registers per lane).
-template <int SCHEME, bool FOLD = true, int EX = kElemF32, int TM = 128>
+template <int SCHEME, bool FOLD = true, int EX = kElemF32, int TM = 128, bool RAGGED = false>
 __global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
                                                                   const unsigned* __restrict__ wmax,
                                                                   const float* __restrict__ xmax,
                                                                   void* __restrict__ dX, int B, int P, int tilesM,
                                                                   int tilesN, int xcd_map, const float* __restrict__ gate) {
   static_assert(TM == 128 || !FOLD, "the 256-row tile has no registers for local chains");
-  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32>;
+  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
@@ -978,6 +985,7 @@ __global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bw
   tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
            (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro);
   tile.for_each([&](int lr, int lc, float v) {
+    if (RAGGED && (ti * TM + lr >= B || tj * 128 + lc >= P)) return;
     const size_t idx = (size_t)m * B * P + (size_t)(ti * TM + lr) * P + tj * 128 + lc;
     const float r = SCHEME == 1 ? v * unscale : v;
     if (EX == kElemF32) static_cast<float*>(dX)[idx] = r;
@@ -1533,7 +1541,7 @@ __global__ __launch_bounds__(256) void gram_transform_bwd_kernel(float* __restri
 template <int T, bool NN, bool VEC>
 __global__ __launch_bounds__(kThreads, 2) void bgemm_kernel(GemmOperands g, float* __restrict__ C, int tilesN, float alpha,
                                                             const float* __restrict__ bias, float beta) {
-  using Tile = GemmTile<T, T, NN, VEC, NoPrologue>;
+  using Tile = GemmTile<T, T, NN, VEC, NoPrologue, kBK, false, true>;     // blocked summation (CHAIN)
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN, b = blockIdx.y;
   NoPrologue pro;
@@ -1547,12 +1555,28 @@ __global__ __launch_bounds__(kThreads, 2) void bgemm_kernel(GemmOperands g, floa
   });
 }
 
+// Tiny products (the toy configs, the hypernetwork's code MLPs: a few hundred thousand multiply-adds, launch-bound on any
+// kernel): one thread per output element, one fused multiply-add per k in k order - the rounding of a CPU dot product,
+// where the fp32 MFMA (products and sums rounded separately, sums truncated) is about 3x noisier.
+template <bool NN>
+__global__ __launch_bounds__(256) void bgemm_fma_kernel(GemmOperands g, float* __restrict__ C, float alpha,
+                                                        const float* __restrict__ bias, float beta) {
+  const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= g.rowsA * g.colsB) return;
+  const int row = idx / g.colsB, col = idx % g.colsB;
+  const float* a = g.A + (size_t)b * g.strideA + (size_t)row * g.lda;
+  const float* bm = g.B + (size_t)b * g.strideB + (NN ? (size_t)col : (size_t)col * g.ldb);
+  float acc = 0.f;
+  for (int k = 0; k < g.K; ++k) acc = fmaf(a[k], NN ? bm[(size_t)k * g.ldb] : bm[k], acc);
+  C[(size_t)b * g.rowsA * g.colsB + idx] = alpha * acc + (bias ? beta * bias[(size_t)b * g.colsB + col] : 0.f);
+}
+
 // split-K form for small outputs over a long K (conv wgrad: [O, C kh kw] summed over N Ho Wo patches): slab z holds the
 // partial product over k in [z kchunk, (z+1) kchunk); splitk_reduce_kernel sums the slabs in a fixed order.
 template <int T, bool NN, bool VEC>
 __global__ __launch_bounds__(kThreads, 2) void bgemm_splitk_kernel(GemmOperands g, float* __restrict__ part, int tilesN,
                                                                    int batch) {
-  using Tile = GemmTile<T, T, NN, VEC, NoPrologue>;
+  using Tile = GemmTile<T, T, NN, VEC, NoPrologue, kBK, false, true>;
   __shared__ typename Tile::Smem sm;
   const int ti = blockIdx.x / tilesN, tj = blockIdx.x % tilesN, b = blockIdx.y, z = blockIdx.z;
   const int kbeg = z * g.kchunk, kend = kbeg + g.kchunk < g.K ? kbeg + g.kchunk : g.K;
@@ -2221,7 +2245,7 @@ __global__ __launch_bounds__(256) void ger_kernel(const float* __restrict__ alph
 
 __device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_df(float z) {
-  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+  return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
 }
 __device__ __forceinline__ float block_sum256(float v, float* red) {
 #pragma unroll
@@ -2288,8 +2312,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restr
   }
 }
 
-// dweight[c] = sum_n dz[n,c] xhat[n,c], dbias[c] = sum_n dz[n,c]: one thread per channel walks the rows in order
-// (deterministic; N is the member count, 128)
+// dweight[c] = sum_n dz[n,c] xhat[n,c], dbias[c] = sum_n dz[n,c] (N is the member count, 128)
 __global__ __launch_bounds__(256) void groupnorm_affine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int N,
                                                                    int C, int G, const float* __restrict__ w,
                                                                    const float* __restrict__ b, const float* __restrict__ mean,
@@ -2334,6 +2357,15 @@ using namespace hecka;
 extern "C" {
 
 int hecka_version(void) { return 6; }
+
+// Ragged shapes take the split-precision 128-row tile when its grid fills the GPU (nwg >= small_grid(): the hypernetwork's
+// 128 members x 400 samples run 1.25 - 1.6x faster on it); a small grid is latency-bound and finishes sooner as 2.5x as
+// many 64-row fp32-MFMA workgroups (MNIST, 5 x 300: 27 vs 43 us - profiles/r02_ragged_ab.txt).  HECKA_RAGGED_X3=1 / 0
+// forces the split-precision tile / the fp32-MFMA kernels for every ragged shape.
+static inline bool ragged_x3_wanted(long long nwg) {
+  const char* e = getenv("HECKA_RAGGED_X3");      // read per call: a test can flip it inside one process
+  return e ? atoi(e) != 0 : nwg >= small_grid();
+}
 
 static inline bool gemm_mode_ok(int mode) {
   return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
@@ -2404,7 +2436,14 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
   const long long nwg = (long long)grid.x * M;
   const bool split_ok = g_gemm_mode != HECKA_GEMM_FP32 && vec && B % T == 0 && P % kX6BK == 0 && nwg < (1ll << 31) &&
                         (long long)B * P < (1ll << 29);
-  if (split_ok && xmax && g_gemm_mode == HECKA_GEMM_AUTO)
+  // ragged shapes (the reference's own batch sizes: 300, 100, 400) on the split-precision tile: whole quads in k and
+  // 16-byte row starts are all it needs (gemm_bf16x6.hpp, RAGGED)
+  const bool ragged_ok = g_gemm_mode == HECKA_GEMM_AUTO && xmax && vec && !split_ok && nwg < (1ll << 31) &&
+                         (long long)B * P < (1ll << 28) && ragged_x3_wanted(nwg);
+  if (ragged_ok)
+    hipLaunchKernelGGL((gram_center_x6_kernel<1, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, xmax, C, cvec, B,
+                       P, ntile, (int)(M % 8 == 0));
+  else if (split_ok && xmax && g_gemm_mode == HECKA_GEMM_AUTO)
     hipLaunchKernelGGL(gram_center_x6_kernel<1>, dim3((unsigned)nwg), dim3(kThreads), 0, st, X, sbar, xmax, C, cvec, B, P,
                        ntile, (int)(M % 8 == 0));
   else if (split_ok)
@@ -2437,7 +2476,7 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
 // workgroups); otherwise every layer is cut into pieces of about d* features, d* = total depth / 1024 (at least 1024),
 // at most 8 per layer.  Returns the workspace bytes (0: no split).
 static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, int* kchunk) {
-  const int ntile = B / 128;
+  const int ntile = (B + 127) / 128;
   const long long per = (long long)M * (ntile * (ntile + 1) / 2);
   long long work = 0;
   for (int i = 0; i < L; ++i) {
@@ -2450,7 +2489,7 @@ static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, in
   size_t bytes = 0;
   for (int i = 0; i < L; ++i) {
     long long ns = std::min<long long>(8, std::max<long long>(1, (P[i] + dstar / 2) / dstar));
-    const long long tiles16 = P[i] / 16;
+    const long long tiles16 = (P[i] + 15) / 16;
     long long kc = ((tiles16 + ns - 1) / ns) * 16;
     ns = (P[i] + kc - 1) / kc;
     nsplit[i] = (int)ns;
@@ -2461,10 +2500,10 @@ static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, in
 }
 
 size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P) {
-  if (L <= 0 || L > kMaxGramLayers || M <= 0 || B <= 0 || B % 128 != 0 || !P) return 0;
+  if (L <= 0 || L > kMaxGramLayers || M <= 0 || B <= 0 || B % 4 != 0 || !P) return 0;
   int ns[kMaxGramLayers], kc[kMaxGramLayers];
   for (int i = 0; i < L; ++i)
-    if (P[i] <= 0 || P[i] % 16 != 0) return 0;
+    if (P[i] <= 0 || P[i] % 4 != 0) return 0;
   return gram_split_plan(L, M, B, P, ns, kc);
 }
 
@@ -2493,16 +2532,21 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
   if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
-  if (M <= 0 || B <= 0 || B % 128 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: needs B %% 128 == 0 (B = %lld)", "", B);
+  if (M <= 0 || B <= 0 || B % 4 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: needs B %% 4 == 0 (B = %lld)", "", B);
   if (g_gemm_mode == HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "gram_center_multi: not available in HECKA_GEMM_FP32 mode%s");
-  const int ntile = B / 128, per = M * (ntile * (ntile + 1) / 2);
+  const int ntile = (B + 127) / 128, per = M * (ntile * (ntile + 1) / 2);
+  bool ragged = B % 128 != 0;      // any layer off the interior shape: the whole launch takes the masked tile
   bool have_max = xmax != nullptr;
   GramMultiArgs a;
   a.L = L;
   a.M = M;
   int nsp[kMaxGramLayers], kch[kMaxGramLayers];
-  for (int i = 0; i < L; ++i)
-    if (P[i] <= 0 || P[i] % 16 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs P %% 16 == 0 (P = %lld)", "", P[i]);
+  for (int i = 0; i < L; ++i) {
+    if (P[i] <= 0 || P[i] % 4 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs P %% 4 == 0 (P = %lld)", "", P[i]);
+    ragged = ragged || P[i] % 16 != 0;
+  }
+  if (ragged && (dtype != HECKA_DT_F32 || g_gemm_mode != HECKA_GEMM_AUTO))
+    return fail(HECKA_EINVAL, "gram_center_multi: ragged shapes (B %% 128, P %% 16) need fp32 features and HECKA_GEMM_AUTO%s");
   const size_t need = ws ? gram_split_plan(L, M, B, P, nsp, kch) : 0;   // no workspace given: no split
   if (need > ws_bytes) return fail(HECKA_EWORKSPACE, "%sgram_center_multi: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   if (!need)
@@ -2512,8 +2556,8 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   long long wg = 0;
   for (int i = 0; i < L; ++i) {
     if (!X[i] || !sbar[i] || !C[i] || !cvec[i]) return fail(HECKA_EINVAL, "gram_center_multi: null layer pointer%s");
-    if (P[i] <= 0 || P[i] % 16 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * es >= (1ll << 32))
-      return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs P %% 16 == 0, 16-byte alignment, B*P*4 < 4 GiB (P = %lld)", "", P[i]);
+    if (!aligned16(X[i]) || !aligned16(sbar[i]) || (long long)B * P[i] * es >= (ragged ? (1ll << 30) : (1ll << 32)))
+      return fail(HECKA_EINVAL, "%sgram_center_multi: layer needs 16-byte alignment, B*P*4 < 4 GiB (1 GiB for ragged shapes) (P = %lld)", "", P[i]);
     if (i > 0 && P[i] > P[i - 1]) return fail(HECKA_EINVAL, "gram_center_multi: layers must come deepest (largest P) first%s");
     have_max = have_max && xmax[i] != nullptr;
     wg += (long long)per * nsp[i];
@@ -2543,6 +2587,10 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
       if (raw) HECKA_GRAM16(kElemF16, true); else HECKA_GRAM16(kElemF16, false);
     }
 #undef HECKA_GRAM16
+  } else if (ragged) {
+    if (!have_max) return fail(HECKA_EINVAL, "gram_center_multi: ragged shapes need xmax%s");
+    hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, true>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B,
+                       ntile, xcd);
   } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
   else
@@ -2939,6 +2987,13 @@ int hecka_bgemm_f32(const float* A, const float* Bm, float* C, int batch, int ro
   const int tilesM = (rows + T - 1) / T, tilesN = (cols + T - 1) / T;
   dim3 grid(tilesM * tilesN, batch);
   hipStream_t st = (hipStream_t)stream;
+  if (K <= 512 && (long long)rows * cols * K <= (1ll << 18) && (long long)batch * rows * cols * K <= (1ll << 23) &&
+      !getenv("HECKA_BGEMM_NO_FMA")) {
+    dim3 gridf((rows * cols + 255) / 256, batch);
+    if (nn) hipLaunchKernelGGL(bgemm_fma_kernel<true>, gridf, dim3(256), 0, st, g, C, alpha, bias, beta);
+    else hipLaunchKernelGGL(bgemm_fma_kernel<false>, gridf, dim3(256), 0, st, g, C, alpha, bias, beta);
+    return check_launch("bgemm");
+  }
 #define HECKA_BGEMM(TT, NNF, V) \
   hipLaunchKernelGGL((bgemm_kernel<TT, NNF, V>), grid, dim3(kThreads), 0, st, g, C, tilesN, alpha, bias, beta)
   if (big) {
@@ -3453,6 +3508,19 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
   const bool split_ok = g_gemm_mode != HECKA_GEMM_FP32 && full && nwg < (1ll << 31) && (long long)B * P < (1ll << 29) &&
                         (long long)B * B < (1ll << 29);
   const unsigned* wm = reinterpret_cast<const unsigned*>(wmax);
+  // ragged B / P on the split-precision tile (W rows need whole, 16-byte aligned quads: B % 4 == 0; X is gathered by dwords)
+  const bool ragged_ok = g_gemm_mode == HECKA_GEMM_AUTO && wmax && xmax && !full && B % 4 == 0 && aligned16(W) &&
+                         nwg < (1ll << 31) && (long long)B * P < (1ll << 28) && (long long)B * B < (1ll << 28) &&
+                         ragged_x3_wanted(nwg);
+  if (ragged_ok) {
+    if (B <= 1024)
+      hipLaunchKernelGGL((gram_bwd_x6_kernel<1, false, kElemF32, 128, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm,
+                         xmax, dX, B, P, tilesM, tilesN, (int)(M % 8 == 0), gate);
+    else
+      hipLaunchKernelGGL((gram_bwd_x6_kernel<1, true, kElemF32, 128, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, W, X, wm,
+                         xmax, dX, B, P, tilesM, tilesN, (int)(M % 8 == 0), gate);
+    return check_launch("gram_bwd");
+  }
   // K = B <= 1024: one accumulation chain (no local 64-k chains): 153 instead of 230 VGPRs, three workgroups per CU,
   // +6 % - the end-to-end gradient error stays 0.7 - 2.5e-6 of max |dX| (with local chains 0.4 - 2.4e-6;
   // tools/grad_margin.py, tools/bwd_accuracy.py).  HECKA_BWD_FOLD=1 keeps the local chains.

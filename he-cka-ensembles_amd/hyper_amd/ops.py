@@ -207,8 +207,9 @@ def centered_gram(X, return_xmax=False, out=None):
 
 def multi_gram_eligible(Xs):
     """All layers can share ONE centred-Gram launch (hecka_gram_center_multi_f32): fp32 GPU features with the same
-    members and samples, B % 128 == 0, every P % 16 == 0, at most 16 layers, split-precision GEMM mode; or 16-bit
-    features that native16_eligible accepts."""
+    members and samples, at most 16 layers, split-precision GEMM mode, and either interior shapes (B % 128 == 0, every
+    P % 16 == 0) or - HECKA_GEMM_AUTO only - ragged ones made of whole quads (B % 4 == 0, every P % 4 == 0: the
+    reference's batch sizes 300 / 100 / 400); or 16-bit features that native16_eligible accepts."""
     if not 2 <= len(Xs) <= 16:
         return False
     if Xs[0].dtype in (torch.bfloat16, torch.float16):
@@ -217,9 +218,16 @@ def multi_gram_eligible(Xs):
     for X in Xs:
         if not (X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.shape[0] == M and X.shape[1] == B):
             return False
-        if X.shape[2] % 16 or B * X.shape[2] * 4 >= 2 ** 32:
+        if X.shape[2] % 4 or X.shape[2] == 0 or B * X.shape[2] * 4 >= 2 ** 30:
             return False
-    return B % 128 == 0 and get_gemm_mode() != 1
+    interior = B % 128 == 0 and all(X.shape[2] % 16 == 0 for X in Xs)
+    if interior:
+        return get_gemm_mode() != 1
+    # ragged: only when the 128-row tiles of ONE layer already fill the GPU (same rule as the library's per-layer dispatch)
+    ntile = (B + 127) // 128
+    want = os.environ.get('HECKA_RAGGED_X3')
+    big = M * ntile * (ntile + 1) // 2 >= int(os.environ.get('HECKA_SMALL_GRID', '384'))
+    return B % 4 == 0 and get_gemm_mode() == 0 and (big if want is None else want != '0')
 
 
 def centered_gram_multi(Xs):

@@ -84,9 +84,18 @@ def test_model_kernel_matches_reference_golden(name):
             assert _relerr(g, rec['gram%d' % i]) <= ref32('gram%d' % i)
 
 
-@pytest.mark.parametrize('M,B,P', [(3, 37, 19), (5, 300, 84), (2, 130, 10), (4, 128, 256), (2, 257, 515), (1, 8, 4)])
-def test_kernels_ragged_shapes(M, B, P):
-    """Each C-ABI entry point at ragged / unaligned sizes against fp64 torch on the CPU."""
+@pytest.mark.parametrize('M,B,P', [(3, 37, 19), (5, 300, 84), (2, 130, 10), (4, 128, 256), (2, 257, 515), (1, 8, 4),
+                                   (5, 300, 864), (30, 100, 40), (128, 400, 256), (3, 132, 20), (2, 1028, 36)])
+@pytest.mark.parametrize('x3', ['auto', 'split'])
+def test_kernels_ragged_shapes(M, B, P, x3, monkeypatch):
+    """Each C-ABI entry point at ragged / unaligned sizes against fp64 torch on the CPU.  The reference's own batch sizes
+    (configs/mnist/base.yml:11,17: 300 (+100 ood); configs/toy/fourclass/base.yml: 100) are ragged: with B % 4 == 0 (and
+    P % 4 == 0 for the Gram) they run on the split-precision tile with masked loads / epilogue when its grid fills the
+    GPU (x3 = 'auto': the library's rule; 'split': HECKA_RAGGED_X3=1 puts every eligible shape on it), otherwise fp32 MFMA."""
+    if x3 == 'split':
+        if B % 4:
+            pytest.skip('no whole quads: fp32 MFMA only')
+        monkeypatch.setenv('HECKA_RAGGED_X3', '1')
     from hyper_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(M * 1000 + B + P)
@@ -104,6 +113,11 @@ def test_kernels_ragged_shapes(M, B, P):
     dC = torch.einsum('ij,jab->iab', A.cpu().double(), Cref)
     W = (dC + dC.transpose(1, 2)) * (1 - torch.eye(B, dtype=torch.float64))
     assert _relerr(dX.cpu().numpy(), (W @ Xd).numpy()) <= 1e-5
+    C2, cvec2, xmax = ops.centered_gram(X, True)          # with xmax the dX GEMM may take the fp16-split tile
+    cref = ((Xd - Xd.mean(1, keepdim=True)) * Xd.mean(1, keepdim=True)).sum(2)
+    assert _relerr(cvec2.cpu().numpy(), cref.numpy()) <= 1e-5
+    dX2 = ops.gram_backward(A, C2, cvec2, X, True, xmax)
+    assert _relerr(dX2.cpu().numpy(), (W @ Xd).numpy()) <= 1e-5
     # un-fused functional pieces
     Kg = ops.linear_gram(X.clone().requires_grad_(True), True)
     assert _relerr(Kg.detach().cpu().numpy(), K.numpy()) <= 2e-6
@@ -155,14 +169,17 @@ def test_bench_shape_properties():
     assert float((d12 - d1 - 2 * d2).abs().max()) <= 2e-5 * float(d12.abs().max())
 
 
-@pytest.mark.parametrize('M,B,P', [(8, 256, 80), (16, 128, 48), (3, 128, 144), (5, 384, 1024), (64, 512, 512)])
-def test_gemm_modes_against_fp64(M, B, P):
+@pytest.mark.parametrize('M,B,P', [(8, 256, 80), (16, 128, 48), (3, 128, 144), (5, 384, 1024), (64, 512, 512),
+                                   (5, 300, 864), (30, 100, 40), (128, 400, 256)])
+def test_gemm_modes_against_fp64(M, B, P, monkeypatch):
     """Interior shapes run the two large GEMMs on the 16-bit matrix cores with exactly split fp32 operands
     (HECKA_GEMM_AUTO: f16x3, HECKA_GEMM_BF16X6); HECKA_GEMM_FP32 forces fp32 MFMA.  All against fp64 torch on
     the GPU, the split paths to the SAME tolerance as the fp32 one (2e-6 of the largest entry for the Gram,
     1e-5 for dX)."""
     from hyper_amd import ops, _lib
     dev = _dev()
+    if B % 128:
+        monkeypatch.setenv('HECKA_RAGGED_X3', '1')      # ragged shapes: mode 0 on the masked split-precision tile
     g = torch.Generator().manual_seed(M + B + P)
     X = (torch.randn(M, B, P, generator=g) ** 3 + 0.25).to(dev)     # skewed, non-zero mean
     Xd = X.double()
@@ -296,6 +313,33 @@ def test_bench_workload_five_layers_against_fp64_oracle(style):
             del xs, out, track
         del ref_grads
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('M,B,dims,force', [(128, 400, (864, 256, 120, 84), False), (5, 300, (864, 256, 120, 84), True),
+                                            (30, 100, (40, 40, 20), True), (9, 132, (20, 36, 1000), True)])
+def test_model_layers_at_the_references_batch_sizes_against_fp64_oracle(M, B, dims, force, monkeypatch):
+    """The reference's own (ragged) batch sizes through the fused `model_layers` node - one masked split-precision Gram
+    launch for all layers (split-K where the grid is small), masked dX GEMMs - against the fp64 oracle on the GPU: the
+    hypernetwork's 128 x (300 + 100) by the library's own dispatch, MNIST 5 x 300 and toy 30 x 100 with the tile forced
+    (HECKA_RAGGED_X3=1; by default their small grids stay on the 64-row fp32-MFMA kernels)."""
+    import bench
+    from hyper_amd import ops
+    from hyper_amd.diversity.model_kernels import build_model_kernel
+    from collections import OrderedDict
+    dev = _dev()
+    if force:
+        monkeypatch.setenv('HECKA_RAGGED_X3', '1')
+    torch.manual_seed(M + B)
+    feats = [torch.randn(M, B, p, device=dev) * (1.0 + i) + 0.3 for i, p in enumerate(dims)]
+    assert ops.multi_gram_eligible(feats)
+    for cfg in (bench.CFG, bench.CFG_EXP):
+        ref_loss, ref_grads = bench.oracle_fp64_on_gpu(cfg, feats)
+        xs = [f.detach().clone().requires_grad_(True) for f in feats]
+        out = build_model_kernel(cfg).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
+        out.backward()
+        rec = bench.parity_record(float(out.item()), [x.grad for x in xs], ref_loss, ref_grads)
+        assert rec['loss_rel'] <= RTOL, rec
+        assert rec['grad_rel_max'] <= RTOL, rec
 
 
 @pytest.mark.parametrize('dtype,native', [('bfloat16', '1'), ('float16', '1'), ('bfloat16', '0'), ('bfloat16', 'exact')])
