@@ -34,7 +34,10 @@ const char* hecka_last_error(void);
  * in the reference (torch.bmm picks its own algorithm).  It is a per-call argument: the library holds no process-wide
  * state, two callers in one process may use different modes.  Interior shapes (B % 128 == 0 and P % 16 == 0
  * resp. P % 128 == 0) run on the 16-bit matrix cores with fp32 operands split EXACTLY into 16-bit terms, partial
- * sums over 64 k folded into the running sum with round-to-nearest fp32 adds; other shapes use fp32 MFMA.
+ * sums over 64 k folded into the running sum with round-to-nearest fp32 adds.  Ragged shapes made of whole quads (B % 4
+ * == 0, P % 4 == 0 for the Gram; the reference's batch sizes 300 / 100 / 400) take the same tile with masked loads and
+ * epilogues under HECKA_GEMM_AUTO when xmax / wmax are given and the grid of 128-row tiles fills the GPU (>= 384
+ * workgroups; HECKA_RAGGED_X3=1 / 0 in the environment forces / forbids it); all other shapes use fp32 MFMA.
  *   HECKA_GEMM_AUTO (default): "f16x3" when the caller supplies the operands' absolute maxima (xmax / wmax below):
  *     x * 2^e = h + l, two fp16 terms (22 significand bits), three products hh + hl + lh per a*b; the power-of-two
  *     scale 2^e comes from the maximum, so an element below 2^-17 of its member's maximum loses relative (not
@@ -65,8 +68,9 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
 
 /* hecka_gram_center_f32 for L tracked layers (same M and B, their own P) in ONE launch: X / sbar / xmax / C / cvec are
  * HOST arrays of L device pointers (xmax, or any xmax[i], may be NULL), P a host array of L feature widths, layers
- * ordered deepest (largest P) first.  Split-precision path only: B % 128 == 0, every P % 16 == 0, L <= 16; callers
- * fall back to per-layer hecka_gram_center_f32 otherwise.  Replaces the Python loop over layers of
+ * ordered deepest (largest P) first.  Split-precision path only, L <= 16: interior shapes (B % 128 == 0, every
+ * P % 16 == 0), or - HECKA_GEMM_AUTO with every xmax given - ragged ones with B % 4 == 0 and every P % 4 == 0 (masked
+ * tile, B * P * 4 < 1 GiB); callers fall back to per-layer hecka_gram_center_f32 otherwise.  Replaces the Python loop over layers of
  * ModelLayersKernel.forward (hyper/diversity/model_kernels.py:446-478) for the Gram stage: one layer alone leaves
  * the second scheduling round of the GPU three-quarters empty (M*10 workgroups on 512 slots at B = 512). */
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
