@@ -180,9 +180,13 @@ def main():
             return loss
         return xs, step
 
+    tok = torch.zeros(1, device=dev)
+
     def barrier():
+        # an all-reduce of one element on the compute stream + a device sync (dist.barrier() on RCCL costs tens of
+        # milliseconds per call, which would sit inside the timed region)
         if dist is not None:
-            dist.barrier()
+            dist.all_reduce(tok)
         torch.cuda.synchronize()
 
     def timed(step, steps, warmup, profile=False):
@@ -192,6 +196,9 @@ def main():
         if profile:
             ops.PROFILE = {'gram_bwd': []}       # HIP events around the dominant kernel, on the launch stream
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        import gc
+        gc.collect()        # a full collection of the interpreter (torch imported: about 40 ms, the host thread stops issuing)
+        gc.disable()        # would otherwise land in the timed region once in a few runs; nothing below makes cycles
         barrier()
         t0 = time.perf_counter()
         evs[0].record()
@@ -200,18 +207,31 @@ def main():
             evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         prof, ops.PROFILE = ops.PROFILE, None
-        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        raw = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+        if os.environ.get('HECKA_BENCH_DEBUG'):
+            print('slowest eval: #%d of %d, %.2f ms' % (max(range(steps), key=lambda i: raw[i]), steps, max(raw)), file=sys.stderr)
+        per = sorted(raw)
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, per, loss, prof
 
+    # the first collective of a process group sets up its channels and RCCL goes on initialising in the background for
+    # some tens of milliseconds (seen as one sporadic 40 - 50 ms stall of the host thread): do it now, long before t0
+    barrier()
     xs, step = workload(CFG, False)
     dt, per, loss, prof = timed(step, args.steps, args.warmup, profile=True)
     loss_val = float(loss.item())
     grads = [x.grad.detach().clone() for x in xs]
+    sent_per_eval = 0
+    if sharded:      # bytes this rank sends per evaluation (hyper_amd.parallel counts what it hands to the collectives)
+        from hyper_amd import parallel
+        b0 = parallel.EXCHANGED_BYTES
+        step()
+        sent_per_eval = parallel.EXCHANGED_BYTES - b0
 
     parity, bad = None, False
     if world == 1 and not sharded and not args.no_parity:
@@ -275,13 +295,14 @@ def main():
                        'workload': 'configs[3] synthetic loss-only microbench: M=64, B=512, P=[512,1024,2048,4096,8192], '
                                    'he (s=2, eps=0.0025, arc_eps=0.031), linear kernel, detach_diag, uniform layer weights',
                        'loss': loss_val, 'algorithmic_tflops_per_s': flops_eval / (ms * 1e-3) / 1e12},
-            'median_ms_device': per[len(per) // 2], 'min_ms_device': per[0],
+            'median_ms_device': per[len(per) // 2], 'min_ms_device': per[0], 'p90_ms_device': per[(9 * len(per)) // 10],
+            'max_ms_device': per[-1],
             'roofline': dict({'bound': 'mfma', 'kernel': kname, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                               'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': traffic}, **hw),
         }
         if world > 1:
             out['per_rank_ms_per_step'] = ms      # max over ranks (each rank runs M/world members)
-            out['exchanged_bytes_per_rank_per_eval'] = ops.EXCHANGED_BYTES // max(args.steps + args.warmup, 1)
+            out['exchanged_bytes_per_rank_per_eval'] = sent_per_eval
         if parity is not None:
             out['parity'] = parity
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only

@@ -138,8 +138,10 @@ struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constan
 // term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
 // ALOW = false: the same for A (both false: one product, hh).
 template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
-          bool BLOW = true, bool ALOW = true, bool SAMEAB = false, bool RAGGED = false>
+          bool BLOW = true, bool ALOW = true, bool SAMEAB = false, bool RAGGED = false, bool ASLICED = false>
 struct GemmTileX6 {
+  // ASLICED: the rows of A lie in blocks of 2^a_rshift rows, block b of this member at element offset b * a_blk (the
+  // member-sharded path keeps W in the order the all-to-all delivers it: [slice, member, rows of the slice, B])
   static_assert(!RAGGED || (!implicit_b<Pro>::value && !implicit_nt<Pro>::value), "ragged tiles: explicit operands only");
   static constexpr unsigned kOOB = 0x80000000u;   // a byte offset no (< 2 GiB) operand reaches: the load returns zero
   // SAMEAB (NT, diagonal tile of a symmetric product): the B rows ARE the A rows - nothing is loaded, split or staged
@@ -156,7 +158,8 @@ struct GemmTileX6 {
 
   // Ab / Bb: this member's operands, bytesA / bytesB their sizes (< 4 GiB: offsets are 32-bit)
   __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb,
-                                      unsigned bytesB, int ldb, int row0, int col0, int kbeg, int kend, Pro& pro) {
+                                      unsigned bytesB, int ldb, int row0, int col0, int kbeg, int kend, Pro& pro,
+                                      int a_rshift = 31, unsigned a_blk = 0) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
     f32x16 loc[MI][NI];
@@ -174,11 +177,18 @@ struct GemmTileX6 {
     const int kq = t & 3, srow = t >> 2;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Ab), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bb), 0, (int)bytesB, 0x00020000);
-    const unsigned sA0 = ((unsigned)row0 * lda + kbeg) * (unsigned)SA;
+    const unsigned sA0 = ((ASLICED ? 0u : (unsigned)row0 * lda) + kbeg) * (unsigned)SA;
     const unsigned sB0 = (NN ? ((unsigned)kbeg * ldb + col0) : ((unsigned)col0 * ldb + kbeg)) * (unsigned)SB;
     unsigned aoff[CA], bgoff[CB];
 #pragma unroll
-    for (int i = 0; i < CA; ++i) aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * (unsigned)SA;
+    for (int i = 0; i < CA; ++i) {
+      if (ASLICED) {
+        const unsigned r = (unsigned)(row0 + srow + 64 * i);
+        aoff[i] = ((r >> a_rshift) * a_blk + (r & ((1u << a_rshift) - 1u)) * lda + 4 * kq) * (unsigned)SA;
+      } else {
+        aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * (unsigned)SA;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < CB; ++i)
       bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) *

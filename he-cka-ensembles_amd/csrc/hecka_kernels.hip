@@ -404,7 +404,7 @@ template <int SCHEME, int EX = kElemF32, bool RAGGED = false>
 __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
-                                                    int w, int kbeg, int kend) {
+                                                    int w, int kbeg, int kend, int slice_rshift = 31, int Mlay = 0) {
   using Pro = CenterProX6<SCHEME, RAGGED>;
   using Tile = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, false, RAGGED>;
   using TileD = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, true, RAGGED>;   // diagonal tiles
@@ -448,15 +448,23 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
     }
   }
   __syncthreads();
-  float* Cm = C + (size_t)m * B * B;
+  // element (row, col) of member m.  Standard: m B^2 + row B + col.  Sliced (slice_rshift < 31, the member-sharded
+  // path): [B >> rshift slices][Mlay members][2^rshift rows][B] - the order the all-to-all sends, so no repacking copy
+  const size_t mstride = slice_rshift < 31 ? ((size_t)B << slice_rshift) : (size_t)B * B;
+  const size_t blk = slice_rshift < 31 ? (size_t)Mlay * mstride : 0;
+  const unsigned rmask = slice_rshift < 31 ? (1u << slice_rshift) - 1u : 0x7fffffffu;
+  float* Cm = C + (size_t)m * mstride;
+  auto at = [&](int row, int col) -> float& {
+    return Cm[(size_t)((unsigned)row >> slice_rshift) * blk + (size_t)((unsigned)row & rmask) * B + col];
+  };
   const int row0 = I * 128, col0 = J * 128;
   if (I == J && threadIdx.x < 128 && (!RAGGED || row0 + (int)threadIdx.x < B))
     cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];
   tile.for_each([&](int lr, int lc, float v) {
     if (RAGGED && (row0 + lr >= B || col0 + lc >= B)) return;     // rows / columns of the padded tile that do not exist
     if (SCHEME == 1) v *= unscale;
-    Cm[(size_t)(row0 + lr) * B + col0 + lc] = v + cB[lc];
-    if (I != J) Cm[(size_t)(col0 + lc) * B + row0 + lr] = v + cA[lr];
+    at(row0 + lr, col0 + lc) = v + cB[lc];
+    if (I != J) at(col0 + lc, row0 + lr) = v + cA[lr];
   });
 }
 
@@ -516,7 +524,8 @@ __global__ __launch_bounds__(256) void gram_split_reduce_kernel(GramMultiArgs a,
 }
 
 template <int SCHEME, int EX = kElemF32, bool RAW = false, bool RAGGED = false>
-__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map) {
+__global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map,
+                                                                           int slice_rshift) {
   static_assert(!(RAW && RAGGED), "the raw 16-bit Gram is written for interior shapes");
   const int w = blockIdx.x;
   int li = 0, w0 = 0;
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
     cvec = cws + (size_t)z * a.M * B;
   }
   if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
-  else gram_center_x6_body<SCHEME, EX, RAGGED>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
+  else gram_center_x6_body<SCHEME, EX, RAGGED>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend, slice_rshift, a.M);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,6 +776,11 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]
   __shared__ float sG[4][32 * RB];   // per wave: gamma[:, a] of the chunk's Gram row a
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, j = lane & 31;
+  // blockIdx.y: layer of a batched call (A [L,Ma,64], C [L,64,N], gamma [L,Ma,B], W [L,Ma,N] contiguous)
+  A += (size_t)blockIdx.y * (32 * RB * 64);
+  C += (size_t)blockIdx.y * 64 * N;
+  gamma += (size_t)blockIdx.y * (32 * RB) * B;
+  W += (size_t)blockIdx.y * (32 * RB) * N;
   for (int e = t; e < 32 * RB * 64; e += 256) {
     const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
     sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
@@ -959,18 +973,17 @@ struct ScaleProX6 {
 // TM = 256 (no local chains only): each wave owns 128 x 64 of a 256 x 128 tile - a staged X tile feeds twice the MFMAs
 // (24 per k-tile per wave behind one barrier), fragment reads and staging work per MFMA fall by a quarter; two
 // workgroups per CU (128 accumulator registers per lane).
-template <int SCHEME, bool FOLD = true, int EX = kElemF32, int TM = 128, bool RAGGED = false>
-__global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
-                                                                  const unsigned* __restrict__ wmax,
-                                                                  const float* __restrict__ xmax,
-                                                                  void* __restrict__ dX, int B, int P, int tilesM,
-                                                                  int tilesN, int xcd_map, const float* __restrict__ gate) {
+template <int SCHEME, bool FOLD, int EX, int TM, bool RAGGED, bool SLICED>
+__device__ __forceinline__ void gram_bwd_x6_body(const float* __restrict__ W, const void* __restrict__ X,
+                                                 const unsigned* __restrict__ wmax, const float* __restrict__ xmax,
+                                                 void* __restrict__ dX, int B, int P, int tilesM, int tilesN, int xcd_map,
+                                                 const float* __restrict__ gate, int w, int M, int slice_rshift) {
   static_assert(TM == 128 || !FOLD, "the 256-row tile has no registers for local chains");
-  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED>;
+  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED, SLICED>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
-  member_tile(tilesM * tilesN, xcd_map, m, tl);
+  member_tile_w(w, tilesM * tilesN, xcd_map, m, tl);
   const int ti = tl % tilesM, tj = tl / tilesM;
   if (gate && *gate == 0.f) {
     if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * 128, B, P, TM, 128);
@@ -982,8 +995,16 @@ __global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bw
   pro.sb = SCHEME == 1 ? pow2_scale(xmax[m], 14) : 1.0f;
   const float unscale = SCHEME == 1 ? 1.0f / (pro.sa * pro.sb) : 1.0f;
   Tile tile;
-  tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
-           (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro);
+  if constexpr (SLICED) {
+    // W as the all-to-all delivers it: [B >> rshift slices][M members][2^rshift rows][B]
+    const unsigned rpg = 1u << slice_rshift, blk = (unsigned)M * rpg * B;
+    const unsigned bytesW = (((unsigned)B >> slice_rshift) - 1u) * blk * 4u + rpg * B * 4u;
+    tile.run(sm, W + (size_t)m * rpg * B, bytesW, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
+             (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro, slice_rshift, blk);
+  } else {
+    tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
+             (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro);
+  }
   tile.for_each([&](int lr, int lc, float v) {
     if (RAGGED && (ti * TM + lr >= B || tj * 128 + lc >= P)) return;
     const size_t idx = (size_t)m * B * P + (size_t)(ti * TM + lr) * P + tj * 128 + lc;
@@ -992,6 +1013,52 @@ __global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bw
     else if (EX == kElemBF16) static_cast<__bf16*>(dX)[idx] = (__bf16)r;
     else static_cast<_Float16*>(dX)[idx] = (_Float16)r;
   });
+}
+
+template <int SCHEME, bool FOLD = true, int EX = kElemF32, int TM = 128, bool RAGGED = false>
+__global__ __launch_bounds__(kThreads, (FOLD || TM == 256) ? 2 : 3) void gram_bwd_x6_kernel(const float* __restrict__ W, const void* __restrict__ X,
+                                                                  const unsigned* __restrict__ wmax,
+                                                                  const float* __restrict__ xmax,
+                                                                  void* __restrict__ dX, int B, int P, int tilesM,
+                                                                  int tilesN, int xcd_map, const float* __restrict__ gate) {
+  gram_bwd_x6_body<SCHEME, FOLD, EX, TM, RAGGED, false>(W, X, wmax, xmax, dX, B, P, tilesM, tilesN, xcd_map, gate,
+                                                       (int)blockIdx.x, 0, 31);
+}
+
+// dX = W X of ALL tracked layers in one launch (fp32 features, f16x3, one accumulation chain: B <= 1024), deepest layer
+// first: a layer alone leaves the tail of its last scheduling round idle - 5 tails per evaluation, and a member shard's
+// small layers (8 members x P = 512: 32 workgroups) do not fill the GPU at all.
+struct BwdLayerArgs {
+  const float* W;
+  const float* X;
+  const unsigned* wmax;
+  const float* xmax;
+  float* dX;
+  int P;
+  int wg_end;   // first workgroup of the next layer
+};
+struct BwdMultiArgs {
+  BwdLayerArgs l[kMaxGramLayers];
+  int L, M;
+};
+
+template <int TM, bool RAGGED, bool SLICED>
+__global__ __launch_bounds__(kThreads, TM == 256 ? 2 : 3) void gram_bwd_x6_multi_kernel(BwdMultiArgs a, int B, int tilesM, int xcd_map,
+                                                                                       const float* __restrict__ gate,
+                                                                                       int slice_rshift) {
+  const int w = blockIdx.x;
+  int li = 0, w0 = 0;
+  while (li + 1 < a.L && w >= a.l[li].wg_end) {
+    w0 = a.l[li].wg_end;
+    ++li;
+  }
+  const float* W = a.l[0].W; const float* X = a.l[0].X; const unsigned* wmax = a.l[0].wmax; const float* xmax = a.l[0].xmax;
+  float* dX = a.l[0].dX; int P = a.l[0].P;
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) { W = a.l[i].W; X = a.l[i].X; wmax = a.l[i].wmax; xmax = a.l[i].xmax; dX = a.l[i].dX; P = a.l[i].P; }
+  gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED>(W, X, wmax, xmax, dX, B, P, tilesM, (P + 127) / 128, xcd_map, gate,
+                                                          w - w0, a.M, slice_rshift);
 }
 
 // General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
@@ -2367,6 +2434,13 @@ static inline bool ragged_x3_wanted(long long nwg) {
   return e ? atoi(e) != 0 : nwg >= small_grid();
 }
 
+static int slice_shift(int B, int slice_rows) {      // log2(slice_rows) for a power of two that divides B, else -1
+  if (slice_rows <= 0 || (slice_rows & (slice_rows - 1)) || B % slice_rows) return -1;
+  int s = 0;
+  while ((1 << s) < slice_rows) ++s;
+  return s;
+}
+
 static inline bool gemm_mode_ok(int mode) {
   return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
 }
@@ -2470,7 +2544,7 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream);
+                                  float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int gemm_mode, void* stream);
 
 // Split-K plan of a multi-layer Gram launch: none while the unsplit grid already fills the GPU twice over (1024
 // workgroups); otherwise every layer is cut into pieces of about d* features, d* = total depth / 1024 (at least 1024),
@@ -2510,24 +2584,27 @@ size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
                                 int B, const int* P, float* const* C, float* const* cvec, int gemm_mode, void* stream) {
   return gram_center_multi_impl(L, reinterpret_cast<const void* const*>(X), HECKA_DT_F32, sbar, xmax, M, B, P, C, cvec,
-                                nullptr, 0, gemm_mode, stream);
+                                nullptr, 0, 0, gemm_mode, stream);
 }
 
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream) {
+                                float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int gemm_mode, void* stream) {
   if (dtype != HECKA_DT_F32 && dtype != HECKA_DT_BF16 && dtype != HECKA_DT_F16) {
     clear_error();
     return fail(HECKA_EINVAL, "gram_center_multi_x16: unknown dtype%s");
   }
-  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, gemm_mode, stream);
+  return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, slice_rows, gemm_mode, stream);
 }
 
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                  float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream) {
+                                  float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int gemm_mode, void* stream) {
   clear_error();
   if (!gemm_mode_ok(gemm_mode)) return fail(HECKA_EINVAL, "gram_center_multi: unknown gemm_mode%s");
+  const int rs = slice_rows ? slice_shift(B, slice_rows) : 31;
+  if (rs < 0 || (slice_rows && dtype != HECKA_DT_F32))
+    return fail(HECKA_EINVAL, "gram_center_multi: slice_rows must be a power of two dividing B (fp32 features only)%s");
   const int g_gemm_mode = gemm_mode;
   const long long es = dtype == HECKA_DT_F32 ? 4 : 2;
   if (L <= 0 || L > kMaxGramLayers) return fail(HECKA_EINVAL, "gram_center_multi: 1..16 layers%s");
@@ -2580,7 +2657,7 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
       return fail(HECKA_EINVAL, "gram_center_multi_x16: 16-bit features need xmax and HECKA_GEMM_AUTO%s");
     const bool raw = !getenv("HECKA_X16_EXACT");
 #define HECKA_GRAM16(E, R) \
-  hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, E, R>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd)
+  hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, E, R>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs)
     if (dtype == HECKA_DT_BF16) {
       if (raw) HECKA_GRAM16(kElemBF16, true); else HECKA_GRAM16(kElemBF16, false);
     } else {
@@ -2590,11 +2667,11 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   } else if (ragged) {
     if (!have_max) return fail(HECKA_EINVAL, "gram_center_multi: ragged shapes need xmax%s");
     hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, true>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B,
-                       ntile, xcd);
+                       ntile, xcd, rs);
   } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
-    hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+    hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs);
   else
-    hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd);
+    hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs);
   if (int rc = check_launch("gram_center_multi")) return rc;
   if (any_split) {
     const long long nC = (long long)M * B * B, nc = (long long)M * B;
@@ -2805,6 +2882,35 @@ int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma,
   if (B <= 0 || n_start < 0 || n_count <= 0 || n_start + n_count > (long long)B * B)
     return fail(HECKA_EINVAL, "combine_slice: the slice must lie inside the B*B Gram%s");
   return combine_impl(A, Cs, gamma, Ma, Mb, n_count, B, detach_diag, Ws, nullptr, stream, 1, n_start);
+}
+
+int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Ma, int Mb,
+                                    int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
+                                    void* stream) {
+  clear_error();
+  if (!A_all || !Cs_all || !gamma_all || !Ws_all) return fail(HECKA_EINVAL, "combine_slice_batched: null pointer%s");
+  if (L <= 0 || L > 65535 || Ma <= 0 || Mb <= 0 || B <= 0 || n_start < 0 || n_count <= 0 || n_start + n_count > (long long)B * B)
+    return fail(HECKA_EINVAL, "combine_slice_batched: bad size, or the slice does not lie inside the B*B Gram%s");
+  const long long N = n_count;
+  const bool stream_ok = Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && N % 64 == 0 && n_start % 64 == 0 &&
+                         aligned16(A_all) && aligned16(Cs_all) && aligned16(gamma_all) && aligned16(Ws_all) &&
+                         64ll * N * 4 < (1ll << 32) && !getenv("HECKA_COMBINE_TILED");
+  if (!stream_ok) {      // other shapes: layer by layer on the tiled kernel
+    for (int l = 0; l < L; ++l)
+      if (int rc = combine_impl(A_all + (size_t)l * Ma * Mb, Cs_all + (size_t)l * Mb * N, gamma_all + (size_t)l * Ma * B, Ma, Mb, N,
+                                B, detach_diag, Ws_all + (size_t)l * Ma * N, nullptr, stream, 1, n_start))
+        return rc;
+    return HECKA_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
+  if (Ma == 64)
+    hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
+                       N, n_start / 64);
+  else
+    hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
+                       N, n_start / 64);
+  return check_launch("combine_slice_batched");
 }
 
 int hecka_wbound_f32(const float* A, const float* nsq, const float* gamma, int Ma, int Mb, int B, float* wbound,
@@ -3553,6 +3659,62 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
   else
     hipLaunchKernelGGL((gram_bwd_kernel<false, false>), grid, dim3(kThreads), 0, st, g, dX, tilesN, gate);
   return check_launch("gram_bwd");
+}
+
+int hecka_gram_bwd_multi_eligible(int L, int M, int B, const int* P, int slice_rows) {
+  if (L <= 0 || L > kMaxGramLayers || M <= 0 || B <= 0 || B > 1024 || B % 4 != 0 || !P) return 0;
+  if (slice_rows && slice_shift(B, slice_rows) < 0) return 0;
+  if ((long long)B * B * M >= (1ll << 28)) return 0;       // (sliced W: one descriptor spans all members)
+  const int tm = (B % 256 == 0) ? 256 : 128, tilesM = (B + tm - 1) / tm;
+  long long wg = 0;
+  bool interior = B % 128 == 0;
+  for (int i = 0; i < L; ++i) {
+    if (P[i] <= 0 || (long long)B * P[i] >= (1ll << 28)) return 0;
+    interior = interior && P[i] % 128 == 0;
+    wg += (long long)M * tilesM * ((P[i] + 127) / 128);
+  }
+  if (wg >= (1ll << 31)) return 0;
+  if (!interior && !ragged_x3_wanted(wg)) return 0;
+  return 1;
+}
+
+int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X, const float* const* wmax,
+                             const float* const* xmax, const float* gate, int M, int B, const int* P, float* const* dX,
+                             int slice_rows, int gemm_mode, void* stream) {
+  clear_error();
+  if (gemm_mode != HECKA_GEMM_AUTO) return fail(HECKA_EINVAL, "gram_bwd_multi: HECKA_GEMM_AUTO only%s");
+  if (!W || !X || !wmax || !xmax || !P || !dX) return fail(HECKA_EINVAL, "gram_bwd_multi: null pointer%s");
+  if (!hecka_gram_bwd_multi_eligible(L, M, B, P, slice_rows))
+    return fail(HECKA_EINVAL, "gram_bwd_multi: shape not eligible (see hecka_gram_bwd_multi_eligible)%s");
+  bool interior = B % 128 == 0;
+  for (int i = 0; i < L; ++i) interior = interior && P[i] % 128 == 0;
+  const int tm = (interior && B % 256 == 0) ? 256 : 128, tilesM = (B + tm - 1) / tm;
+  BwdMultiArgs a;
+  a.L = L;
+  a.M = M;
+  long long wg = 0;
+  for (int i = 0; i < L; ++i) {
+    if (!W[i] || !X[i] || !wmax[i] || !xmax[i] || !dX[i]) return fail(HECKA_EINVAL, "gram_bwd_multi: null layer pointer%s");
+    if (!aligned16(W[i]) || !aligned16(X[i])) return fail(HECKA_EINVAL, "gram_bwd_multi: needs 16-byte alignment%s");
+    wg += (long long)M * tilesM * ((P[i] + 127) / 128);
+    a.l[i] = BwdLayerArgs{W[i], X[i], reinterpret_cast<const unsigned*>(wmax[i]), xmax[i], dX[i], P[i], (int)wg};
+  }
+  for (int i = L; i < kMaxGramLayers; ++i) a.l[i] = a.l[L - 1];
+  hipStream_t st = (hipStream_t)stream;
+  const int xcd = (int)(M % 8 == 0), rs = slice_rows ? slice_shift(B, slice_rows) : 31;
+#define HECKA_BWDM(TMV, RAG, SL) \
+  hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<TMV, RAG, SL>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, tilesM, xcd, gate, rs)
+  if (slice_rows) {
+    if (tm == 256) HECKA_BWDM(256, false, true);
+    else if (interior) HECKA_BWDM(128, false, true);
+    else HECKA_BWDM(128, true, true);
+  } else {
+    if (tm == 256) HECKA_BWDM(256, false, false);
+    else if (interior) HECKA_BWDM(128, false, false);
+    else HECKA_BWDM(128, true, false);
+  }
+#undef HECKA_BWDM
+  return check_launch("gram_bwd_multi");
 }
 
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate, int M,

@@ -38,7 +38,7 @@ SIGNATURES = {
     'hecka_gram_center_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'hecka_wbound_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'hecka_colmean_x16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     'hecka_gram_center_multi_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
     'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'hecka_head_fwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -69,9 +69,12 @@ SIGNATURES = {
     'hecka_conv_wgrad_x3_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'hecka_conv_wgrad_x3_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp, _sz, _vp]),
     'hecka_combine_slice_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
+    'hecka_combine_slice_batched_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'hecka_batchnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'hecka_gram_bwd_multi_eligible': (_i, [_i, _i, _i, _vp, _i]),
+    'hecka_gram_bwd_multi_f32': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
 }
 
 

@@ -15,7 +15,6 @@ from . import _lib
 # kernel's launches on the launch stream; None in normal operation.
 PROFILE = None
 LAST_BWD_KERNEL = None     # name of the kernel the last dX launch took (bench.py's `roofline.kernel`)
-EXCHANGED_BYTES = 0        # bytes this rank handed to collectives (hyper_amd/parallel.py adds to it; bench.py reports it)
 
 
 # ---- arithmetic of the two large GEMMs (include/hecka.h HECKA_GEMM_*): 0 auto (f16x3), 1 fp32 MFMA, 2 bf16x6 ---------------
@@ -230,9 +229,10 @@ def multi_gram_eligible(Xs):
     return B % 4 == 0 and get_gemm_mode() == 0 and (big if want is None else want != '0')
 
 
-def centered_gram_multi(Xs):
+def centered_gram_multi(Xs, slice_rows=0):
     """[X_l [M,B,P_l]] -> [(C_l, cvec_l, xmax_l)]: the column-mean passes, then every layer's centred Gram in one
-    launch, deepest layer first (no autograd)."""
+    launch, deepest layer first (no autograd).  slice_rows (a power of two dividing B; fp32 features): C_l comes as
+    [B / slice_rows, M, slice_rows, B] - the send order of the member-sharded exchange - instead of [M, B, B]."""
     import ctypes
     L = _lib.lib()
     M, B = Xs[0].shape[0], Xs[0].shape[1]
@@ -262,7 +262,9 @@ def centered_gram_multi(Xs):
     _lib.check(L.hecka_gram_center_multi_x16(
         n, ptrs([Xs[i] for i in order]), dt, ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
         Ps, ptrs([out[i][0] for i in order]), ptrs([out[i][1] for i in order]),
-        _p(ws) if ws is not None else None, nbytes, get_gemm_mode(), st), 'gram_center_multi')
+        _p(ws) if ws is not None else None, nbytes, int(slice_rows), get_gemm_mode(), st), 'gram_center_multi')
+    if slice_rows:
+        return [(C.view(B // slice_rows, M, slice_rows, B), cvec, xmax) for C, cvec, xmax, _ in out]
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
 
 
@@ -328,6 +330,17 @@ def combine_slice(A, Cs, gamma, B, n_start, detach_diag):
     return Ws
 
 
+def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag):
+    """combine_slice for all layers in one launch: A_all [L,Ma,Mb], Cs_all [L,Mb,n], gamma_all [L,Ma,B] -> Ws_all [L,Ma,n]."""
+    Ln, Ma, Mb = A_all.shape
+    n = Cs_all.shape[2]
+    Ws = torch.empty((Ln, Ma, n), device=Cs_all.device, dtype=torch.float32)
+    if n:
+        _lib.check(_lib.lib().hecka_combine_slice_batched_f32(_p(A_all), _p(Cs_all), _p(gamma_all), Ln, Ma, Mb, B, n_start, n,
+                                                              int(bool(detach_diag)), _p(Ws), _stream()), 'combine_slice_batched')
+    return Ws
+
+
 def wbound(A, nsq, gamma):
     """[Ma] upper bounds of max |W_i| (hecka_wbound_f32)."""
     Ma, Mb = A.shape
@@ -356,6 +369,47 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
         LAST_BWD_KERNEL = 'gram_bwd_x6_kernel<1, false, 0, %d>' % tile
     _GemmChain.leave(X.device, chain)
     return dX
+
+
+def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
+    """Every layer's dX = W X in ONE launch (hecka_gram_bwd_multi_f32): fp32 features, f16x3 mode with all maxima."""
+    import ctypes
+    if not 2 <= len(Xs) <= 16 or get_gemm_mode() != 0 or os.environ.get('HECKA_BWD_MULTI', '1') == '0':
+        return False
+    if any(w is None for w in wmaxs) or any(x is None for x in xmaxs):
+        return False
+    M, B = Xs[0].shape[0], Xs[0].shape[1]
+    if any(X.dtype != torch.float32 or X.shape[0] != M or X.shape[1] != B for X in Xs):
+        return False
+    Ps = (ctypes.c_int * len(Xs))(*[X.shape[2] for X in Xs])
+    return bool(_lib.lib().hecka_gram_bwd_multi_eligible(len(Xs), M, B, Ps, int(slice_rows)))
+
+
+def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
+    """[dX_l] = [W_l X_l] for all layers in one launch, deepest layer first.  slice_rows: W_l lies as
+    [B / slice_rows, M, slice_rows, B] (see centered_gram_multi)."""
+    import ctypes
+    n = len(Xs)
+    M, B = Xs[0].shape[0], Xs[0].shape[1]
+    order = sorted(range(n), key=lambda i: -Xs[i].shape[2])
+    dXs = [torch.empty_like(X) for X in Xs]
+    ptrs = lambda ts: (ctypes.c_void_p * n)(*[ts[i].data_ptr() for i in order])   # noqa: E731
+    Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
+    chain = _GemmChain.enter(Xs[0].device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.lib().hecka_gram_bwd_multi_f32(n, ptrs(Ws), ptrs(Xs), ptrs(wmaxs), ptrs(xmaxs), _gp(gate), M, B, Ps,
+                                                  ptrs(dXs), int(slice_rows), get_gemm_mode(), _stream()), 'gram_bwd_multi')
+    if PROFILE is not None:
+        e1.record()
+        PROFILE['gram_bwd'].append((e0, e1, sum(2.0 * M * B * B * X.shape[2] for X in Xs)))
+        global LAST_BWD_KERNEL
+        interior = B % 128 == 0 and all(X.shape[2] % 128 == 0 for X in Xs)
+        LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s>' % (256 if interior and B % 256 == 0 else 128,
+                                                                     'false' if interior else 'true', 'true' if slice_rows else 'false')
+    _GemmChain.leave(Xs[0].device, chain)
+    return dXs
 
 
 def _stacked(ts):
@@ -509,10 +563,14 @@ class DiversityLayers(torch.autograd.Function):
         A_all = head_backward_batched(S_all, nsq_all, 0, specs, dout, scales)
         gamma_all = coef_gamma_batched(A_all, cv_all)
         wmax_all = wbound_batched(A_all, nsq_all, gamma_all)
+        wmaxs = [wmax_all[li] for li in range(Ln)]
+        if gram_bwd_multi_eligible(Cs, Xs, wmaxs, xmaxs):      # every W, then ONE dX launch for all layers
+            Ws = [combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag) for li in range(Ln)]
+            return (None,) + tuple(gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, ctx.gate))
         grads = []
         for li in range(Ln):
             W = combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag)
-            grads.append(gram_bwd_w(W, Xs[li], wmax_all[li], xmaxs[li], ctx.gate))
+            grads.append(gram_bwd_w(W, Xs[li], wmaxs[li], xmaxs[li], ctx.gate))
         return (None,) + tuple(grads)
 
 

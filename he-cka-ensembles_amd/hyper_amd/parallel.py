@@ -32,6 +32,14 @@ import torch
 import torch.distributed as dist
 
 
+EXCHANGED_BYTES = 0      # bytes this rank has SENT through the collectives below (bench.py reports it per evaluation)
+
+
+def _sent(nbytes):
+    global EXCHANGED_BYTES
+    EXCHANGED_BYTES += int(nbytes)
+
+
 class _Done:
     def wait(self):
         return True
@@ -42,6 +50,8 @@ def _staged(group, *ts):
 
 
 def _all_to_all(out, inp, out_splits, in_splits, group):
+    world = dist.get_world_size(group)
+    _sent(inp.numel() * inp.element_size() * (world - 1) // world)
     if _staged(group, out, inp):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
@@ -51,6 +61,7 @@ def _all_to_all(out, inp, out_splits, in_splits, group):
 
 
 def _all_gather(out, inp, group):
+    _sent(inp.numel() * inp.element_size() * (dist.get_world_size(group) - 1))
     if _staged(group, out, inp):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(o, inp.cpu(), group=group)
@@ -60,6 +71,8 @@ def _all_gather(out, inp, group):
 
 
 def _all_reduce(t, group):
+    world = dist.get_world_size(group)
+    _sent(2 * t.numel() * t.element_size() * (world - 1) // world)      # ring: reduce-scatter + all-gather
     if _staged(group, t):
         o = t.cpu()
         dist.all_reduce(o, op=dist.ReduceOp.SUM, group=group)
@@ -89,7 +102,13 @@ class _SlicedLayers(torch.autograd.Function):
         even = all(n == n_r for n in ns)
         feats = [X.contiguous() for X in feats]
         multi = getattr(backend, 'multi_gram_eligible', None)
-        pre = backend.centered_gram_multi(feats) if multi is not None and multi(feats) else None
+        multi = multi is not None and multi(feats)
+        # slice-major Grams: when a slice is whole rows (a power of two of them) the Gram epilogue writes C straight in
+        # the all-to-all's send order [G, Ml, rows, B] and the dX GEMM reads W in the order it arrives - no repacking
+        rows = n_r // B if (even and n_r % B == 0) else 0
+        sliced = (world > 1 and multi and rows > 0 and rows & (rows - 1) == 0 and feats[0].dtype == torch.float32 and
+                  hasattr(backend, 'gram_bwd_multi') and os.environ.get('HECKA_SHARD_REPACK', '0') != '1')
+        pre = (backend.centered_gram_multi(feats, slice_rows=rows) if sliced else backend.centered_gram_multi(feats)) if multi else None
         slices, cvecs, xmaxs = [], [], []
         # every layer's column slice in ONE buffer: the batched pairwise stage reads it whole
         Cs_all = None
@@ -101,7 +120,9 @@ class _SlicedLayers(torch.autograd.Function):
             if world == 1:
                 slices.append((C2, _Done()))
             else:
-                if even:      # [Ml, G, n] -> [G, Ml, n] in one strided copy
+                if sliced:
+                    send = C2.view(-1)
+                elif even:      # [Ml, G, n] -> [G, Ml, n] in one strided copy
                     send = C2.view(Ml, world, n_r).permute(1, 0, 2).contiguous().view(-1)
                 else:
                     send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
@@ -147,6 +168,8 @@ class _SlicedLayers(torch.autograd.Function):
         ctx.batch = (S_all, nsq_all, cv_all, specs, scales) if batched else None
         ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
         ctx.geom = (world, rank, Ml, B, bounds, ns)
+        ctx.sliced = rows if sliced else 0
+        ctx.Cs_all = Cs_all
         ctx.gate = getattr(backend, 'current_gate', lambda: None)()     # ops.grad_gate: a masked NaN term gives dX = 0
         ctx.mode = getattr(backend, 'get_gemm_mode', lambda: None)()
         return total.clone()
@@ -164,27 +187,42 @@ class _SlicedLayers(torch.autograd.Function):
         r0, n_r, N2 = rank * Ml, ns[rank], B * B
         dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
         pending = []
+        Ws_all = wmax_all = None
         if ctx.batch is not None:   # one head_bwd and one gamma launch for all layers
             S_all, nsq_all, cv_stack, specs, scales = ctx.batch
             A_all = be.head_backward_batched(S_all, nsq_all, 0, specs, dloss, scales)
             gamma_all = be.coef_gamma_batched(A_all, cv_stack)
+            if world > 1 and ctx.Cs_all is not None and hasattr(be, 'combine_slice_batched'):   # ... and one combine launch
+                Ws_all = be.combine_slice_batched(A_all, ctx.Cs_all, gamma_all, B, bounds[rank], ctx.detach)
+            if hasattr(be, 'wbound_batched') and all(s[7] is not None for s in ctx.saved):
+                wmax_all = be.wbound_batched(A_all[:, r0:r0 + Ml].contiguous(), nsq_all, gamma_all[:, r0:r0 + Ml].contiguous())
         for li, (X, Cs, cv_all, S, nsq, spec, scale, xmax) in enumerate(ctx.saved):
             if ctx.batch is not None:
                 A, gamma = A_all[li], gamma_all[li]
             else:
                 A = be.head_backward(S, nsq, 0, spec, dloss, scale)              # [M, M], the same on every rank
                 gamma = be.coef_gamma(A, cv_all)                                 # [M, B]
-            Ws = be.combine_slice(A, Cs, gamma, B, bounds[rank], ctx.detach)     # [M, n_r]
+            Ws = Ws_all[li] if Ws_all is not None else be.combine_slice(A, Cs, gamma, B, bounds[rank], ctx.detach)   # [M, n_r]
             if world == 1:
                 recv, work = Ws, _Done()
             else:
                 recv = torch.empty((Ml * N2,), device=Ws.device, dtype=Ws.dtype)
                 work = _all_to_all(recv, Ws.view(-1), [Ml * n for n in ns], [Ml * n_r] * world, group)
             wmax = None
-            if xmax is not None and hasattr(be, 'wbound'):
+            if wmax_all is not None:
+                wmax = wmax_all[li]
+            elif xmax is not None and hasattr(be, 'wbound'):
                 wmax = be.wbound(A[r0:r0 + Ml].contiguous(), nsq, gamma[r0:r0 + Ml].contiguous())
             pending.append((X, recv, work, wmax, xmax))
-        grads = []
+        gate = (ctx.gate,) if ctx.gate is not None else ()
+        if ctx.sliced and be.gram_bwd_multi_eligible([p[1] for p in pending], [p[0] for p in pending], [p[3] for p in pending],
+                                                      [p[4] for p in pending], ctx.sliced):
+            for p in pending:
+                p[2].wait()
+            # W stays as it arrived, [G, Ml, rows, B]: ONE dX launch for all layers reads it in that order
+            return (None,) + tuple(be.gram_bwd_multi([p[1] for p in pending], [p[0] for p in pending], [p[3] for p in pending],
+                                                     [p[4] for p in pending], *gate, slice_rows=ctx.sliced))
+        Wl = []
         for X, recv, work, wmax, xmax in pending:
             work.wait()
             if world == 1:
@@ -197,8 +235,12 @@ class _SlicedLayers(torch.autograd.Function):
                 for g in range(world):
                     W[:, bounds[g]:bounds[g + 1]] = recv[off:off + Ml * ns[g]].view(Ml, ns[g])
                     off += Ml * ns[g]
-            gate = (ctx.gate,) if ctx.gate is not None else ()
-            grads.append(be.gram_bwd_w(W.view(Ml, B, B), X, wmax, xmax, *gate))
+            Wl.append(W.view(Ml, B, B))
+        multi = getattr(be, 'gram_bwd_multi_eligible', None)
+        if multi is not None and multi(Wl, [p[0] for p in pending], [p[3] for p in pending], [p[4] for p in pending]):
+            return (None,) + tuple(be.gram_bwd_multi(Wl, [p[0] for p in pending], [p[3] for p in pending],
+                                                     [p[4] for p in pending], *gate))
+        grads = [be.gram_bwd_w(W, X, wmax, xmax, *gate) for W, (X, _, _, wmax, xmax) in zip(Wl, pending)]
         return (None,) + tuple(grads)
 
 

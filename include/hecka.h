@@ -161,6 +161,12 @@ int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamm
  * hyper/experiments/training.py:686-695). */
 int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma, int Ma, int Mb, int B,
                             long long n_start, long long n_count, int detach_diag, float* Ws, void* stream);
+/* hecka_combine_slice_f32 for L layers in one launch: A_all [L,Ma,Mb], Cs_all [L,Mb,n_count], gamma_all [L,Ma,B],
+ * Ws_all [L,Ma,n_count], all contiguous, the same slice [n_start, n_start + n_count) of every layer (a member shard's
+ * slice is 1/G of a Gram: one layer alone is a launch-bound 17 MB). */
+int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Ma, int Mb,
+                                    int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
+                                    void* stream);
 
 /* Upper bound of max |W_i| from what already exists: wbound[i] = 2 sum_j |A[i,j]| sqrt(nsq[j]) + 2 max_b |gamma[i,b]|
  * (nsq[j] = ||C_j||_F^2, the diagonal of hecka_pairwise_f32's S).  Accepted by hecka_gram_bwd_f32 in place of the exact
@@ -359,11 +365,14 @@ int hecka_crater_maxpool2_f32(const float* x, const float* dy, float* out, long 
 int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar, float* xmax, void* stream);
 /* ws: hecka_gram_center_multi_workspace_bytes(L, M, B, P) bytes (0 = none needed; NULL = never split).  With few
  * workgroups over deep layers (small ensembles, a member shard of a multi-GPU run) the launch splits layers over K into
- * partial Grams in ws and sums them in a fixed order - every stage of the epilogue is linear in the k range. */
+ * partial Grams in ws and sums them in a fixed order - every stage of the epilogue is linear in the k range.
+ * slice_rows (hecka_gram_center_multi_x16, fp32 features): 0 = C[l] is [M,B,B]; a power of two dividing B = C[l] is
+ * written as [B / slice_rows][M][slice_rows][B], the send order of the member-sharded all-to-all (hyper_amd/parallel.py)
+ * - no repacking copy between the Gram and the exchange; hecka_gram_bwd_multi_f32 reads W in the same order. */
 size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P);
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* ws, size_t ws_bytes, int gemm_mode, void* stream);
+                                float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int gemm_mode, void* stream);
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate,
                        int M, int B, int P, void* dX, int gemm_mode, void* stream);
 
@@ -375,6 +384,19 @@ int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wm
  * host); here the caller sets *gate = 0 on the device instead, so that no 0 * NaN product reaches the feature gradients. */
 int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const float* xmax, const float* gate, int M, int B,
                        int P, float* dX, int gemm_mode, void* stream);
+
+/* hecka_gram_bwd_f32 for L tracked layers (same M and B, their own P) in ONE launch, as hecka_gram_center_multi_f32 is for
+ * the forward: W / X / wmax / xmax / dX are HOST arrays of L device pointers, P a host array of widths (deepest first fills
+ * the GPU best).  Replaces the per-layer backward of ModelLayersKernel.forward's loop (hyper/diversity/model_kernels.py:
+ * 446-478): a layer alone leaves the tail of its last scheduling round idle, and a member shard's small layers do not
+ * fill the GPU.  f16x3 only (HECKA_GEMM_AUTO, wmax and xmax required), B <= 1024, B % 4 == 0; ragged B / P as in
+ * hecka_gram_bwd_f32.  slice_rows: 0, or a power of two dividing B - W then lies as the member-sharded all-to-all
+ * delivers it, [B / slice_rows][M][slice_rows][B] (no repacking copy).  hecka_gram_bwd_multi_eligible says whether the
+ * call applies; callers use per-layer hecka_gram_bwd_f32 otherwise. */
+int hecka_gram_bwd_multi_eligible(int L, int M, int B, const int* P, int slice_rows);
+int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X, const float* const* wmax,
+                             const float* const* xmax, const float* gate, int M, int B, const int* P, float* const* dX,
+                             int slice_rows, int gemm_mode, void* stream);
 
 #ifdef __cplusplus
 }

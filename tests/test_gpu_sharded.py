@@ -50,6 +50,64 @@ def test_combine_slice_equals_full_combine(M, B):
                 assert torch.equal(Ws, W.view(M, N2)[:, s:e]), (world, g)
 
 
+@pytest.mark.parametrize('M,B,Ps,rows', [(8, 512, (2048, 512, 128), 64), (16, 128, (256, 128), 32), (64, 512, (1024, 512), 0),
+                                          (8, 256, (384, 128), 128), (128, 400, (256, 864), 0), (8, 384, (256, 128), 0)])
+def test_multi_layer_dx_and_slice_major_layouts_are_bit_equal(M, B, Ps, rows, monkeypatch):
+    """ONE dX launch for all layers (hecka_gram_bwd_multi_f32) == the per-layer launches, bit for bit (same tile code,
+    same accumulation order) - interior and ragged shapes; and with `rows` > 0 the slice-major layouts of the member-
+    sharded path: the Gram written as [B/rows, M, rows, B] is the standard Gram permuted, and dX from a W in that order
+    equals dX from the standard W."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    if B % 128:
+        monkeypatch.setenv('HECKA_RAGGED_X3', '1')
+    torch.manual_seed(M + B)
+    Xs = [torch.randn(M, B, p, device=dev) * (1 + i) for i, p in enumerate(Ps)]
+    Ws = [torch.randn(M, B, B, device=dev) for _ in Ps]
+    wmaxs = [W.abs().amax(dim=(1, 2)) for W in Ws]
+    xmaxs = [X.abs().amax(dim=(1, 2)) for X in Xs]
+    assert ops.gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs)
+    one = [ops.gram_bwd_w(W, X, wm, xm) for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)]
+    many = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    ref = Ws[0].double() @ Xs[0].double()
+    assert float((many[0].double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+    gate = torch.zeros(1, device=dev)
+    assert all(float(g.abs().max()) == 0.0 for g in ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate))
+    if rows:
+        G = B // rows
+        Wsl = [W.view(M, G, rows, B).permute(1, 0, 2, 3).contiguous() for W in Ws]
+        assert ops.gram_bwd_multi_eligible(Wsl, Xs, wmaxs, xmaxs, rows)
+        for a, b in zip(one, ops.gram_bwd_multi(Wsl, Xs, wmaxs, xmaxs, slice_rows=rows)):
+            assert torch.equal(a, b)
+        std = ops.centered_gram_multi(Xs)
+        sl = ops.centered_gram_multi(Xs, slice_rows=rows)
+        for (C, cvec, xmax), (Cs, cvs, xms) in zip(std, sl):
+            assert Cs.shape == (G, M, rows, B)
+            assert torch.equal(C.view(M, G, rows, B).permute(1, 0, 2, 3), Cs)
+            assert torch.equal(cvec, cvs) and torch.equal(xmax, xms)
+
+
+@pytest.mark.parametrize('M,Ml,B,world', [(64, 64, 128, 4), (64, 32, 512, 8), (12, 12, 40, 2)])
+def test_batched_combine_slice_equals_per_layer(M, Ml, B, world):
+    """hecka_combine_slice_batched_f32 (one launch for all layers; the streaming kernel at 64 members, layer by layer on
+    the tiled kernel otherwise) == hecka_combine_slice_f32 per layer, bit for bit."""
+    from hyper_amd import ops
+    from hyper_amd.parallel import slice_bounds
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    L = 3
+    bounds = slice_bounds(B * B, world, ops.SLICE_GRANULE)
+    s, e = bounds[1], bounds[2]
+    A = torch.randn(L, Ml, M, device=dev) / M
+    Cs = torch.randn(L, M, e - s, device=dev)
+    gamma = torch.randn(L, Ml, B, device=dev)
+    Wb = ops.combine_slice_batched(A, Cs, gamma, B, s, True)
+    for l in range(L):
+        assert torch.equal(Wb[l], ops.combine_slice(A[l], Cs[l], gamma[l], B, s, True)), l
+
+
 def _case(name):
     torch.manual_seed(17)
     M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9)), 'm64b512': (64, 512, (2048, 256))}[name]
