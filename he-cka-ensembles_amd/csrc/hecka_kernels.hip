@@ -415,7 +415,11 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   member_tile_w(w, ntile * (ntile + 1) / 2, xcd_map, m, rem);
   int I, J;
   tri_tile(rem, ntile, I, J);
+#ifdef HECKA_EXP_ALIAS   // experiment only (csrc/lab): every member reads member 0's features - no HBM traffic to speak of
+  const char* Xm = static_cast<const char*>(X);
+#else
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * ES;
+#endif
   Pro pro;
   pro.klim = P;
   pro.sbar = sbar + (size_t)m * P;

@@ -6,7 +6,7 @@ product path raises.  Build it with `make -C he-cka-ensembles_amd/csrc` (or `__g
 import ctypes
 import os
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhecka.so')
+_PATH = os.environ.get('HECKA_LIB_PATH') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libhecka.so')
 _lib = None
 
 _vp, _i, _ll, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_size_t, ctypes.c_double
