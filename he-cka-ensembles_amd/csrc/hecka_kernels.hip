@@ -597,6 +597,12 @@ __global__ __launch_bounds__(kThreads, 2) void pairwise_kernel(GemmOperands g, f
 // 512 threads (two waves per SIMD), next step's loads in flight during the 48 MFMAs of the current one; the eight waves'
 // accumulators are added in wave order through LDS and the workgroup writes one partial slab (fixed-order second stage
 // as before).  fp32-MFMA-bound: 1.6 GFLOP at M = 64, B = 512.
+// X6 = true: the same products on the bf16 matrix cores - every staged value is split exactly into three bf16 terms by the
+// lane that holds it (each (row, k) sits in exactly one lane: no value is split twice) and a.b is the six leading
+// products (gemm_bf16x6.hpp: no scaling, no range assumption, error <= 4e-7 of sum|a.b|); 36 MFMAs of 32 cycles per 32-k
+// step instead of 48 of 64.  One local accumulation chain per step (32 k), folded into the running sum with v_add_f32.
+// Moves the kernel from the fp32-MFMA floor (68 us for five layers) to the HBM side.
+template <bool X6>
 __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __restrict__ C, long long K, int steps_per_wave,
                                                                float* __restrict__ part) {
   // per-wave staging tile: 64 rows x 32 k (128 B) at a 144-byte pitch (conflict-free ds_read_b128 down a column of rows);
@@ -640,21 +646,61 @@ __global__ __launch_bounds__(512) void pairwise_self64_kernel(const float* __res
     to_lds();
   }
   while (st < s1) {
-    if (st + 1 < s1) gload(st + 1);                 // next step's lines in flight behind this step's 48 MFMAs
-    f32x4 f0[4], f1[4];
+    if (st + 1 < s1) gload(st + 1);                 // next step's lines in flight behind this step's MFMAs
+    if constexpr (X6) {
+      // lane (r, kh) holds C[r][16 b + 8 kh .. + 7] and C[32 + r][same k] of k-block b: the A fragment of a row block and
+      // the B fragment of the same column block are the same registers here too
+      f32x16 loc[3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f0[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 8 * u]);
-      f1[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 32 * kPitch + 8 * u]);
-    }
+      for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+        for (int q = 0; q < 16; ++q) loc[b][q] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f0[u][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f1[u][e], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[u][e], f1[u][e], acc[2], 0, 0, 0);
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 p0[3], p1[3];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float* src = &mine[(half ? 32 * kPitch : 0) + r * kPitch + 16 * kb + 8 * kh];
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+          u32x4 ph, pm, pl;
+          split2(lo, 0, ph, pm, pl, 0);
+          split2(lo, 2, ph, pm, pl, 1);
+          split2(hi, 0, ph, pm, pl, 2);
+          split2(hi, 2, ph, pm, pl, 3);
+          bf16x8* dst = half ? p1 : p0;
+          dst[0] = __builtin_bit_cast(bf16x8, ph);
+          dst[1] = __builtin_bit_cast(bf16x8, pm);
+          dst[2] = __builtin_bit_cast(bf16x8, pl);
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest products first: lh hh... order as in the GEMM tile
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          loc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0[PA[e]], p0[PB[e]], loc[0], 0, 0, 0);
+          loc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0[PA[e]], p1[PB[e]], loc[1], 0, 0, 0);
+          loc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1[PA[e]], p1[PB[e]], loc[2], 0, 0, 0);
+        }
       }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][q] += loc[b][q];
+    } else {
+      f32x4 f0[4], f1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f0[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 8 * u]);
+        f1[u] = *reinterpret_cast<const f32x4*>(&mine[rofs + 32 * kPitch + 8 * u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f0[u][e], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[u][e], f1[u][e], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[u][e], f1[u][e], acc[2], 0, 0, 0);
+        }
+    }
     ++st;
     if (st < s1) to_lds();                          // the wave's own reads above have returned: program order
   }
@@ -2445,6 +2491,12 @@ static int slice_shift(int B, int slice_rows) {      // log2(slice_rows) for a p
   return s;
 }
 
+// HECKA_PAIRWISE_FP32=1: the streaming pairwise kernel on fp32 MFMA (default: bf16x6 split, same accuracy class)
+static inline bool pairwise_x6() {
+  const char* e = getenv("HECKA_PAIRWISE_FP32");
+  return !(e && atoi(e) != 0);
+}
+
 static inline bool gemm_mode_ok(int mode) {
   return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
 }
@@ -2708,7 +2760,10 @@ static int pairwise_launch(const float* Ca, int Ma, const float* Cb, int Mb, lon
   if (Ca == Cb && Ma == 64 && Mb == 64 && K % 32 == 0 && vec && 64 * K * 4 < (1ll << 31) && !getenv("HECKA_PAIRWISE_TILED")) {
     const long long nsteps = K / 32;
     const int spw = (int)((nsteps + (long long)nsplit * 8 - 1) / ((long long)nsplit * 8));
-    hipLaunchKernelGGL(pairwise_self64_kernel, dim3(nsplit), dim3(512), 0, st, Ca, K, spw, part);
+    if (pairwise_x6())
+      hipLaunchKernelGGL(pairwise_self64_kernel<true>, dim3(nsplit), dim3(512), 0, st, Ca, K, spw, part);
+    else
+      hipLaunchKernelGGL(pairwise_self64_kernel<false>, dim3(nsplit), dim3(512), 0, st, Ca, K, spw, part);
   } else if (full)
     hipLaunchKernelGGL((pairwise_kernel<true, true>), grid, dim3(kThreads), 0, st, g, part, tilesN);
   else if (vec)
@@ -2803,7 +2858,10 @@ int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long 
   }
   const long long nsteps = K / 32;
   const int spw = (int)((nsteps + (long long)nsplit * 8 - 1) / ((long long)nsplit * 8));
-  hipLaunchKernelGGL(pairwise_self64_kernel, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws);
+  if (pairwise_x6())
+    hipLaunchKernelGGL(pairwise_self64_kernel<true>, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws);
+  else
+    hipLaunchKernelGGL(pairwise_self64_kernel<false>, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws);
   if (int rc = check_launch("pairwise_self_batched")) return rc;
   const int n = M * M;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, nsplit, n, S_all, 1.0f);

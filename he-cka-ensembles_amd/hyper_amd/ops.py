@@ -564,9 +564,10 @@ class DiversityLayers(torch.autograd.Function):
         gamma_all = coef_gamma_batched(A_all, cv_all)
         wmax_all = wbound_batched(A_all, nsq_all, gamma_all)
         wmaxs = [wmax_all[li] for li in range(Ln)]
-        if gram_bwd_multi_eligible(Cs, Xs, wmaxs, xmaxs):      # every W, then ONE dX launch for all layers
-            Ws = [combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag) for li in range(Ln)]
-            return (None,) + tuple(gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, ctx.gate))
+        if gram_bwd_multi_eligible(Cs, Xs, wmaxs, xmaxs):      # every W in ONE combine launch, then ONE dX launch
+            M, B = Xs[0].shape[0], Xs[0].shape[1]
+            W_all = combine_slice_batched(A_all, _stacked(Cs).view(Ln, M, B * B), gamma_all, B, 0, detach_diag)
+            return (None,) + tuple(gram_bwd_multi([W_all[li] for li in range(Ln)], Xs, wmaxs, xmaxs, ctx.gate))
         grads = []
         for li in range(Ln):
             W = combine_full(A_all[li], Cs[li], gamma_all[li], detach_diag)
