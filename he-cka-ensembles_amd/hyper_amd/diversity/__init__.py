@@ -73,8 +73,17 @@ def pairwise_cka(features, kernel='linear', detach_diag=True, *args, **kwargs):
 
 def hyperspherical_energy(features, s=0.0, half_space=False, eps=3e-5, arc_eps=3e-4, offset=0.0, reduction='mean',
                           remove_diag=True, detach_right=False, abs_vals=False, use_exp=False):
-    if half_space:
-        raise NotImplementedError('half_space=True is never used by the reference model kernels and is not built')
     S, nsq = _inner(features, detach_right)
     cos = cos_from_inner(S, nsq, eps, detach_right)
+    if half_space:
+        # the reference appends the negated, DETACHED unit vectors (:98-105): cos of [u; -u_d] with itself is
+        #   [[ u.u^T , -u.u_d^T ], [ -u_d.u^T , u_d.u_d^T ]]   (every right factor detached too under detach_right)
+        if detach_right:
+            cos_r = cos
+        else:
+            S_r, nsq_r = _inner(features, True)
+            cos_r = cos_from_inner(S_r, nsq_r, eps, True)
+        cos_d = cos.detach()
+        lower_left = -cos_d if detach_right else -cos_r.t()
+        cos = torch.cat([torch.cat([cos, -cos_r], dim=1), torch.cat([lower_left, cos_d], dim=1)], dim=0)
     return energy_from_cos(cos, s, eps, arc_eps, remove_diag, abs_vals, use_exp)

@@ -68,6 +68,10 @@ def host_scalar(owner, param):
 
 
 
+# (model_bs, bs, arc_eps, eps) -> (min, max) energies of normalize=True, shared by all kernels of a process (:257)
+HE_VALUE_CACHE = {}
+
+
 @register_model_kernel('feature')
 class FeatureKernel(BaseModelKernel):
     """Batched Gram over tracked features [M,B,*].  `params` become fp32 0-dim Parameters under
@@ -219,9 +223,6 @@ class HEModelKernel(_PairwiseHead):
     def __init__(self, feature_kernel, he_s=2.0, eps=1e-6, arc_eps=1e-3, center=True, reduction='off_diag',
                  abs_vals=False, detach_right=False, use_exp=False, normalize=False, learnable=False):
         super().__init__()
-        if normalize:
-            raise NotImplementedError('normalize=True (min/max energy pre-solve) is enabled by no shipped config '
-                                      'and is not built')
         self.feature_kernel = feature_kernel
         self.center = center
         self.abs_vals = abs_vals
@@ -241,9 +242,46 @@ class HEModelKernel(_PairwiseHead):
             return arc.item(), eps.item()
         return arc, eps
 
+    @torch.enable_grad()
+    def precompute(self, model_bs, bs, device='cuda'):
+        """Min / max energy of `model_bs` Grams of `bs` samples for normalize=True (model_kernels.py:302-367): the minimum
+        from 100 Adam steps on random unit vectors (lr 0.05, x 0.1 every 10 steps), the "maximum" from a tight Gaussian
+        cluster far from the origin.  Random start on the device: the values differ from run to run, as in the reference."""
+        from . import hyperspherical_energy, unit_vector_rows
+        fake = torch.empty(model_bs, bs, bs, requires_grad=True, dtype=torch.float32, device=device)
+        torch.nn.init.normal_(fake)
+        optim = torch.optim.Adam([fake], lr=0.05)
+        sched = torch.optim.lr_scheduler.StepLR(optim, step_size=10, gamma=0.1)
+        arc, eps = self.get_smoothing(detach=True, asfloat=True)
+        kw = dict(half_space=False, s=self.he_s, arc_eps=arc, eps=eps, use_exp=self.use_exp,
+                  remove_diag=self.reduction == 'off_diag', detach_right=self.detach_right, abs_vals=self.abs_vals)
+        for _ in range(100):
+            optim.zero_grad()
+            with torch.no_grad():
+                fake.data = unit_vector_rows(fake.data, eps=0.0).reshape(model_bs, bs, bs)
+            energy = hyperspherical_energy(fake, **kw).mean()
+            energy.backward()
+            optim.step()
+            sched.step()
+        self.min_he_energy = energy.min().item()
+        with torch.no_grad():
+            torch.nn.init.normal_(fake, mean=1000.0, std=0.1)
+            self.max_he_energy = hyperspherical_energy(fake, **kw).max().item()
+        if self.normalize_he:
+            HE_VALUE_CACHE[(model_bs, bs, arc, eps)] = (self.min_he_energy, self.max_he_energy)
+        return self.min_he_energy, self.max_he_energy
+
+    def _normalized(self, energy, model_bs, bs, device):
+        """(energy - min) / (max - min) with the pre-solved (cached) extremes (model_kernels.py:396-405)."""
+        arc, eps = self.get_smoothing()
+        min_he, max_he = HE_VALUE_CACHE.get((model_bs, bs, arc.item(), eps.item()), (None, None))
+        if min_he is None or max_he is None:
+            min_he, max_he = self.precompute(model_bs, bs, device=device)
+        return (energy - min_he) / (max_he - min_he)
+
     def _spec(self):
-        if not (self.center and self.feature_kernel.fusable) or self._learnable():
-            return None
+        if not (self.center and self.feature_kernel.fusable) or self._learnable() or self.normalize_he:
+            return None      # (normalize: the affine map is applied to the un-fused head's values)
         return ops.HeadSpec(ops.HEAD_HE, s=self.he_s, eps=host_scalar(self, self.eps), arc_eps=host_scalar(self, self.arc_eps),
                             use_exp=self.use_exp, abs_vals=self.abs_vals, remove_diag=self.reduction == 'off_diag',
                             detach_right=self.detach_right)
@@ -253,7 +291,11 @@ class HEModelKernel(_PairwiseHead):
             return self._select(self._values(feats, track))
         arc, eps = self.get_smoothing()
         cos = self._cosine(feats, eps, track)
-        return energy_from_cos(cos, self.he_s, eps, arc, self.reduction == 'off_diag', self.abs_vals, self.use_exp)
+        energy = energy_from_cos(cos, self.he_s, eps, arc, self.reduction == 'off_diag', self.abs_vals, self.use_exp)
+        if self.normalize_he:
+            gram = track['gram']
+            energy = self._normalized(energy, gram.shape[0], gram.shape[1], gram.device)
+        return energy
 
 
 @register_model_kernel('model_layers')

@@ -348,8 +348,6 @@ class Conv2d(_ConvNd):
         super().__init__(in_channels, out_channels, _pair(kernel_size), _pair(stride),
                          padding if isinstance(padding, str) else _pair(padding), _pair(dilation), False, _pair(0),
                          groups, bias, padding_mode, act, gamma, param_scale, track)
-        if groups != 1:
-            raise NotImplementedError('hyper_amd Conv2d: groups > 1 is not built (no shipped config uses it)')
 
     def _geometry(self):
         if self.padding_mode != 'zeros' or isinstance(self.padding, str):
@@ -372,8 +370,22 @@ class Conv2d(_ConvNd):
             lead = x.shape[:-3]
             x = F.pad(x.reshape((-1,) + x.shape[-3:]), self._reversed_padding_repeated_twice, mode=mode)
             x = x.reshape(lead + x.shape[-3:])
-        y = BatchedConv2d.apply(x, W, viewed['bias'] if self.bias else None, self.scale, self.bias_scale,
-                                self._geometry())
+        b = viewed['bias'] if self.bias else None
+        g = self.groups
+        if g == 1:
+            y = BatchedConv2d.apply(x, W, b, self.scale, self.bias_scale, self._geometry())
+        else:
+            # grouped convolution (conv.py:334): group k of member m is its own small convolution - fold the groups into
+            # the member dimension, run the same batched kernels on M * g "members", unfold
+            O, Cg = W.shape[1], W.shape[2]
+            if x.ndim == 4:
+                x = x.unsqueeze(0).expand((M,) + tuple(x.shape))
+            N = x.shape[1]
+            xg = x.reshape((M, N, g, Cg) + tuple(x.shape[-2:])).permute(0, 2, 1, 3, 4, 5).reshape((M * g, N, Cg) + tuple(x.shape[-2:]))
+            yg = BatchedConv2d.apply(xg.contiguous(), W.reshape((M * g, O // g, Cg) + tuple(W.shape[3:])).contiguous(),
+                                     b.reshape(M * g, O // g).contiguous() if b is not None else None, self.scale, self.bias_scale,
+                                     self._geometry())
+            y = yg.reshape((M, g, N, O // g) + tuple(yg.shape[-2:])).permute(0, 2, 1, 3, 4, 5).reshape((M, N, O) + tuple(yg.shape[-2:]))
         if (self.act is activation.crater and self.pooling is F.max_pool2d
                 and activation.crater_maxpool2_eligible(y, self.pooling_kwargs)):
             return activation.crater_maxpool2(y).contiguous()      # act -> 2x2 max pool in one pass

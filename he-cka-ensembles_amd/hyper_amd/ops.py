@@ -695,6 +695,13 @@ def linear_gram(X, detach_diag=True):
     return LinearGram.apply(_features_f32(X), detach_diag)
 
 
+def cross_gram(X, Y):
+    """K_m = X_m Y_m^T for X [M,N,P], Y [M,L,P]: libhecka's grouped GEMM, differentiable in both operands (the general
+    path of diversity/kernels.py: Grams between two sample sets)."""
+    from .layers.linear import BatchedLinear
+    return BatchedLinear.apply(_features_f32(X).contiguous(), _features_f32(Y).contiguous(), None, 1.0, 1.0)
+
+
 class CenterRows(torch.autograd.Function):
     """gram - rowmean(gram) over the last dim; self-adjoint, so backward is the same kernel."""
 

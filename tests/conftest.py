@@ -19,7 +19,7 @@ def golden_cases(tag):
     """Model-kernel fixtures (the train-step fixtures `toy_*` / `lenet_*` / `resnet_*` / `hyper_*` and the layer fixtures `conv_*` have
     their own tests)."""
     return sorted(f[:-len('_%s.npz' % tag)] for f in os.listdir(GOLDEN)
-                  if f.endswith('_%s.npz' % tag) and not f.startswith(('toy_', 'lenet_', 'resnet_', 'svgd_', 'conv_', 'hyper_', 'uhsic_', 'wsvgd_', 'fsvgd_', 'learned_')))
+                  if f.endswith('_%s.npz' % tag) and not f.startswith(('toy_', 'lenet_', 'resnet_', 'svgd_', 'conv_', 'hyper_', 'uhsic_', 'wsvgd_', 'fsvgd_', 'learned_', 'functional_')))
 
 
 def load_golden(name, tag):

@@ -566,6 +566,10 @@ CONV_CASES = {
                             gamma='crater'), 2, (5, 2, 7, 7)),
     'conv_reflect_1x1': (dict(in_channels=3, out_channels=2, kernel_size=1, padding=1, padding_mode='reflect',
                               param_scale='torch'), 2, (2, 3, 3, 6, 5)),
+    'conv_groups2_member': (dict(in_channels=4, out_channels=6, kernel_size=3, padding=1, groups=2, act='relu',
+                                 param_scale='torch'), 3, (3, 5, 4, 8, 7)),
+    'conv_depthwise_shared': (dict(in_channels=3, out_channels=6, kernel_size=3, stride=2, padding=1, groups=3, bias=False,
+                                   param_scale='gamma', gamma=1.0), 2, (4, 3, 9, 9)),
 }
 
 
@@ -601,6 +605,92 @@ def run_uhsic():
     print('uhsic', rec['v0'], rec['v2'])
 
 
+def run_functional():
+    """The rarely used options of the functional API (hyper/diversity/kernels.py, hyper/diversity/__init__.py,
+    HEModelKernel normalize) run through the REAL reference in float64: readd_diag=False, Y != None Grams, log /
+    hyperenergy / learned Grams, a learnable rbf bandwidth, grad_var, EMA median bandwidth, EMA centring, half_space,
+    normalize=True (with the min / max energies of the pre-solve placed in the reference's own cache, so that the
+    fixture pins the arithmetic and not a 100-step Adam run on device noise).  One npz: `<case>/x`, `/y`, `/up`, `/out`,
+    `/dx`, `/dy`, ...."""
+    import random
+    import torch.nn as nn
+    from hyper.diversity import kernels as rk, hyperspherical_energy as ref_he
+    import hyper.diversity.model_kernels as rmk
+    gen = torch.Generator().manual_seed(77)
+    M, N, L, P = 4, 7, 5, 6
+    rec = {}
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=gen, dtype=torch.float64)
+
+    def case(name, fn, X, Y=None, extra=None):
+        X = X.clone().requires_grad_(True)
+        Yv = Y.clone().requires_grad_(True) if Y is not None else None
+        out = fn(X, Yv)
+        up = rnd(*out.shape)
+        (out * up).sum().backward()
+        rec[name + '/x'], rec[name + '/up'], rec[name + '/out'], rec[name + '/dx'] = X.detach().numpy(), up.numpy(), out.detach().numpy(), X.grad.numpy()
+        if Yv is not None:
+            rec[name + '/y'] = Yv.detach().numpy()
+            rec[name + '/dy'] = Yv.grad.numpy() if Yv.grad is not None else np.zeros(tuple(Yv.shape))
+        for k, v in (extra() if extra else {}).items():
+            rec[name + '/' + k] = v
+        print('functional', name, tuple(out.shape))
+
+    X, Y = rnd(M, N, P), rnd(M, L, P)
+    case('linear_readd_false', lambda x, y: rk.batched_gram(x, None, 'linear', True, False, True), X)
+    case('linear_cross', lambda x, y: rk.batched_gram(x, y, 'linear', False, True, False), X, Y)
+    case('linear_cross_centered', lambda x, y: rk.batched_gram(x, y, 'linear', False, True, True), X, Y)
+    case('log', lambda x, y: rk.batched_gram(x, None, 'log', True, True, True), X)
+    case('cossim_readd_false', lambda x, y: rk.batched_gram(x, None, 'cossim', True, False, True), X)
+    case('cossim_cross', lambda x, y: rk.batched_gram(x, y, 'cossim', False, True, False), X, Y)
+    case('hyperenergy', lambda x, y: rk.batched_gram(x, None, 'hyperenergy', True, True, True, arc_eps=0.005, eps=1e-4, mhe_s=2), X)
+    case('rbf_readd_false', lambda x, y: rk.batched_gram(x, None, 'rbf', True, False, True, param=1.7, median=True), X)
+    case('rbf_cross_fixed', lambda x, y: rk.batched_gram(x, y, 'rbf', False, True, False, param=1.3, median=False), X, Y)
+    case('rbf_cross_median_detach_right', lambda x, y: rk.batched_gram(x, y, 'rbf', False, True, True, param=0.8, median=True, detach_right=True), X, Y)
+    # learnable bandwidth: one scalar and one per member
+    for nm, p0 in (('rbf_learn_scalar', torch.tensor(1.4, dtype=torch.float64)), ('rbf_learn_members', torch.tensor([0.9, 1.1, 1.6, 2.0], dtype=torch.float64))):
+        par = p0.clone().requires_grad_(True)
+        case(nm, lambda x, y: rk.batched_gram(x, None, 'rbf', True, True, True, param=par, median=False), X,
+             extra=lambda: {'param': par.detach().numpy(), 'dparam': par.grad.numpy()})
+    # grad_var: (grams, d sum(grams) / d grad_var)
+    Xg = X.clone().requires_grad_(True)
+    g, dg = rk.rbf_gram(Xg, None, param=1.2, median=True, detach_diag=True, readd=True, grad_var=Xg)
+    rec['rbf_grad_var/x'], rec['rbf_grad_var/out'], rec['rbf_grad_var/grad'] = Xg.detach().numpy(), g.detach().numpy(), dg.numpy()
+    # EMA median bandwidth: three calls, the second and third update the moving average with a randomly picked member
+    ma = rk.EMA(0.9).train()
+    random.seed(3)
+    Xs = [X, X * 1.5 + 0.2, X * 0.7]
+    for i, Xi in enumerate(Xs):
+        case('rbf_ema_%d' % i, lambda x, y: rk.batched_gram(x, None, 'rbf', True, True, True, param=1.1, median=True, median_ma=ma, median_update=True), Xi,
+             extra=lambda: {'shadow': ma.shadow.detach().numpy().copy()})
+    case('rbf_ema_frozen', lambda x, y: rk.batched_gram(x, None, 'rbf', True, True, True, param=1.1, median=True, median_ma=ma, median_update=False), X)
+    # EMA centring
+    cma = rk.EMA(0.8).train()
+    for i, Xi in enumerate(Xs):
+        case('center_ema_%d' % i, lambda x, y: rk.batched_gram(x, None, 'linear', True, True, True, ma=cma, update_ma=True), Xi,
+             extra=lambda: {'shadow': cma.shadow.detach().numpy().copy()})
+    # learned Gram: a shared feature model in front of the linear kernel
+    torch.manual_seed(5)
+    model = nn.Linear(P, 5).double()
+    case('learned_linear', lambda x, y: rk.batched_gram(x, None, 'learned', True, True, True, model=model, learned_kernel='linear'), X,
+         extra=lambda: {'w': model.weight.detach().numpy(), 'b': model.bias.detach().numpy(),
+                        'dw': model.weight.grad.numpy().copy(), 'db': model.bias.grad.numpy().copy()})
+    # half-space energy on a batch of Grams
+    G = rnd(5, 6, 6)
+    for nm, kw in (('half_space', {}), ('half_space_detach_right', {'detach_right': True}), ('half_space_exp_all', {'use_exp': True, 'remove_diag': False})):
+        case(nm, lambda x, y: ref_he(x, s=2.0, half_space=True, eps=0.0025, arc_eps=0.031, **kw), G)
+    # normalize=True: min / max energies from the cache
+    kern = rmk.build_model_kernel(he(eps=0.0025, arc_eps=0.031, normalize=True)).double()
+    arc, eps = kern.get_smoothing()
+    Mn, Bn = 5, 9
+    rmk.HE_VALUE_CACHE[(Mn, Bn, arc.item(), eps.item())] = (0.37, 2.9)
+    feats = rnd(Mn, Bn, 11)
+    case('he_normalize', lambda x, y: kern(None, x, None, {}), feats, extra=lambda: {'minmax': np.array([0.37, 2.9])})
+    np.savez_compressed(os.path.join(OUT, 'functional_f64.npz'), **rec)
+    print('functional:', len(rec), 'arrays')
+
+
 def f32_twins():
     """The reference's OWN float32 run of the train-step fixtures (same seeds, same inputs cast to float32): how far the
     reference in float32 sits from the reference in float64 is the yardstick for every test tolerance above 1e-5.  Only
@@ -619,6 +709,16 @@ def f32_twins():
 
 def main():
     mk = _import_reference()
+    if '--conv-groups' in sys.argv:
+        for name in ('conv_groups2_member', 'conv_depthwise_shared'):
+            kwargs, M, xshape = CONV_CASES[name]
+            rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
+            np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)
+            print(name, 'y', rec['y'].shape, float(np.abs(rec['y']).mean()))
+        return
+    if '--functional' in sys.argv:
+        run_functional()
+        return
     if '--uhsic-only' in sys.argv:
         run_uhsic()
         return
@@ -650,6 +750,7 @@ def main():
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
     run_uhsic()
+    run_functional()
     for name, (kwargs, M, xshape) in CONV_CASES.items():
         rec = run_conv_case(name, kwargs, M, xshape, torch.float64)
         np.savez_compressed(os.path.join(OUT, '%s_f64.npz' % name), **rec)

@@ -526,7 +526,8 @@ def _check_step(yard, track, hyper, keys=('pred', 'ind_rep_loss', 'loss')):
         yard.check('g:' + k, v.grad.cpu().numpy())
 
 
-CONV_CASES = ['conv_shared_gamma', 'conv_member_torch_nobias', 'conv_dilated_rect', 'conv_same_even', 'conv_reflect_1x1']
+CONV_CASES = ['conv_shared_gamma', 'conv_member_torch_nobias', 'conv_dilated_rect', 'conv_same_even', 'conv_reflect_1x1',
+              'conv_groups2_member', 'conv_depthwise_shared']      # the last two: groups > 1 (conv.py:334), folded into members
 
 
 @pytest.mark.parametrize('name', CONV_CASES)

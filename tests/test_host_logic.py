@@ -73,8 +73,10 @@ def test_conv_module_shapes_scales_and_errors():
     assert _out_size(10, 3, 1, 2, 2) == 10 and _out_size(9, 2, 2, 0, 1) == 4
     with pytest.raises(ValueError):
         Conv2d(3, 8, 3, padding='same', stride=2)
-    with pytest.raises(NotImplementedError):
-        Conv2d(4, 8, 3, groups=2)
+    g = Conv2d(4, 8, 3, groups=2)            # grouped: weight [O, C / groups, kh, kw], fan-in of one group (conv.py:93-100)
+    assert g.weight_shape == (8, 2, 3, 3) and g.fan_in == 18
+    with pytest.raises(ValueError):
+        Conv2d(4, 6, 3, groups=4)
     with pytest.raises(RuntimeError):        # CPU tensors are refused: there is no CPU path
         c({'self': torch.zeros(2, c.single_flat_size())}, torch.zeros(2, 3, 9, 9))
 
