@@ -354,6 +354,17 @@ def run_hyper_step(dtype, tag):
                 step=1500, seed=63, has_ood_loss=True)
 
 
+def run_hyper_cifar_step(dtype, tag):
+    """BASELINE.json configs[4] names a CIFAR-10 hypernetwork; the reference ships no such config, and its
+    resnet18 cannot be generated (BatchNorm buffers).  The stand-in tools/train_bench.py times: the MNIST hypernetwork of
+    configs/mnist/hyper/mlp-he.yml generating a LeNet-5 with 3 input channels (flatten 16*5*5) on CIFAR-shaped input."""
+    import copy
+    cfg = copy.deepcopy(HYPER)
+    cfg['hyper']['layer_code_generator']['target'] = {'name': 'lenet5', 'in_channels': 3, 'num_classes': 10, 'flatten_dims': 400}
+    _hyper_step(cfg, 'hyper_cifar_train_step', dtype, tag, members=4, latent=38, xshape=(14, 3, 32, 32), n_in=10, classes=10,
+                step=1500, seed=65, has_ood_loss=True)
+
+
 def _hyper_step(CFG, name, dtype, tag, members, latent, xshape, n_in, classes, step, seed, has_ood_loss):
     """One training step of configs/mnist/hyper/mlp-he.yml (the `hyper:` and `method:` sections as shipped, 4 members)
     with the REAL reference: latent -> code mixer MLP -> layer generators (spectral-norm Linear + GroupNorm + GELU)
@@ -697,7 +708,7 @@ def f32_twins():
     the outputs are kept (losses, predictions, gradients, running statistics): the inputs and weights are those of the
     float64 fixture."""
     for fn, name in ((run_resnet_step, 'resnet_train_step'), (run_svgd_step, 'svgd_step'), (run_wsvgd_step, 'wsvgd_step'),
-                     (run_hyper_step, 'hyper_train_step'), (run_hyper_toy_step, 'hyper_toy_train_step'),
+                     (run_hyper_step, 'hyper_train_step'), (run_hyper_toy_step, 'hyper_toy_train_step'), (run_hyper_cifar_step, 'hyper_cifar_train_step'),
                      (run_learned_step, 'learned_step'), (run_fsvgd_step, 'fsvgd_step'))[(5 if '--f32-twins-rest' in sys.argv else 0):]:
         fn(torch.float32, 'f32')
         path = os.path.join(OUT, '%s_f32.npz' % name)
@@ -709,6 +720,13 @@ def f32_twins():
 
 def main():
     mk = _import_reference()
+    if '--hyper-cifar' in sys.argv:
+        run_hyper_cifar_step(torch.float64, 'f64')
+        run_hyper_cifar_step(torch.float32, 'f32')
+        path = os.path.join(OUT, 'hyper_cifar_train_step_f32.npz')
+        z = np.load(path, allow_pickle=False)
+        np.savez_compressed(path, **{k: z[k] for k in z.files if not (k.startswith('w:') or k in ('X', 'Y', 'config'))})
+        return
     if '--conv-groups' in sys.argv:
         for name in ('conv_groups2_member', 'conv_depthwise_shared'):
             kwargs, M, xshape = CONV_CASES[name]
@@ -749,6 +767,7 @@ def main():
     run_learned_step(torch.float64, 'f64')
     run_hyper_step(torch.float64, 'f64')
     run_hyper_toy_step(torch.float64, 'f64')
+    run_hyper_cifar_step(torch.float64, 'f64')
     run_uhsic()
     run_functional()
     for name, (kwargs, M, xshape) in CONV_CASES.items():

@@ -21,7 +21,8 @@ sys.path[:0] = [os.path.join(HERE, 'golden')]
 from fill import fill_state, grad_digest  # noqa: E402
 from conftest import GOLDEN, Yardstick  # noqa: E402
 
-FIXTURES = ['hyper_train_step', 'hyper_toy_train_step']      # configs/mnist/hyper/mlp-he.yml, configs/toy/fourclass/hyper/mlp.yml
+FIXTURES = ['hyper_train_step', 'hyper_toy_train_step',     # configs/mnist/hyper/mlp-he.yml, configs/toy/fourclass/hyper/mlp.yml
+            'hyper_cifar_train_step']                      # BASELINE configs[4] stand-in: the MNIST hypernetwork on 3 x 32 x 32 input
 
 
 def _build(dtype, name='hyper_train_step'):
