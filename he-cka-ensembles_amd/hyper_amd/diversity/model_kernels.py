@@ -57,7 +57,10 @@ def host_scalar(owner, param):
     """float(param) without a device round trip on every call: the value is read back once and cached against
     the parameter's version counter and storage (in-place updates, load_state_dict and .to() all change one of
     them).  A `float(p)` on a device parameter is a blocking copy; four of them per layer per evaluation
-    serialised the layer streams behind whatever GEMM grid owned the GPU."""
+    serialised the layer streams behind whatever GEMM grid owned the GPU.
+    NOT seen: writes through `param.data` (`p.data.fill_(v)`, `p.data = t` onto the same storage) - `.data` has its own
+    version counter.  Update eps / arc_eps / rbf param with `p.copy_()` / `p.fill_()` under no_grad or load_state_dict,
+    or call `refresh_host_scalars(kernel)` after a `.data` write."""
     cache = owner.__dict__.setdefault('_host_scalars', {})
     key = (id(param), param._version, param.data_ptr())
     hit = cache.get(id(param))
@@ -66,6 +69,11 @@ def host_scalar(owner, param):
         cache[id(param)] = hit
     return hit[1]
 
+
+def refresh_host_scalars(module):
+    """Drop the cached host copies of every scalar parameter under `module` (see host_scalar)."""
+    for m in module.modules():
+        m.__dict__.pop('_host_scalars', None)
 
 
 # (model_bs, bs, arc_eps, eps) -> (min, max) energies of normalize=True, shared by all kernels of a process (:257)
