@@ -106,7 +106,8 @@ class _SlicedLayers(torch.autograd.Function):
         # slice-major Grams: when a slice is whole rows (a power of two of them) the Gram epilogue writes C straight in
         # the all-to-all's send order [G, Ml, rows, B] and the dX GEMM reads W in the order it arrives - no repacking
         rows = n_r // B if (even and n_r % B == 0) else 0
-        sliced = (world > 1 and multi and rows > 0 and rows & (rows - 1) == 0 and feats[0].dtype == torch.float32 and
+        sliced = (world > 1 and multi and rows > 0 and rows & (rows - 1) == 0 and
+                  feats[0].dtype in getattr(backend, 'SLICED_DTYPES', (torch.float32,)) and
                   hasattr(backend, 'gram_bwd_multi') and os.environ.get('HECKA_SHARD_REPACK', '0') != '1')
         pre = (backend.centered_gram_multi(feats, slice_rows=rows) if sliced else backend.centered_gram_multi(feats)) if multi else None
         slices, cvecs, xmaxs = [], [], []

@@ -86,3 +86,76 @@ def combine_slice(A, Cs, gamma, B, n_start, detach_diag):
 
 def gram_bwd_w(W, X, wmax=None, xmax=None):
     return _t(np.einsum('mab,mbp->map', W.numpy(), X.double().numpy())).to(X.dtype)
+
+
+# ---- the batched / slice-major stages (ops.centered_gram_multi(slice_rows), gram_bwd_multi, combine_slice_batched, ...):
+# offered only under CPU_BACKEND_MULTI=1 so that the gloo tests cover both the per-layer and the batched branches of
+# hyper_amd.parallel
+import os
+
+SLICED_DTYPES = (torch.float32, torch.float64)
+CALLS = {}      # which batched stages ran (the gloo test asserts the branch it means to cover was taken)
+
+
+def _multi():
+    return os.environ.get('CPU_BACKEND_MULTI') == '1'
+
+
+def multi_gram_eligible(Xs):
+    return _multi() and len(Xs) >= 2
+
+
+def centered_gram_multi(Xs, slice_rows=0):
+    CALLS['gram_multi_sliced' if slice_rows else 'gram_multi'] = CALLS.get('gram_multi_sliced' if slice_rows else 'gram_multi', 0) + 1
+    out = []
+    for X in Xs:
+        C, c, xmax = centered_gram(X, True)
+        if slice_rows:      # [M,B,B] -> [B/rows, M, rows, B]: the send order of the all-to-all
+            M, B = C.shape[0], C.shape[1]
+            C = C.view(M, B // slice_rows, slice_rows, B).permute(1, 0, 2, 3).contiguous()
+        out.append((C, c, xmax))
+    return out
+
+
+def pairwise_self_batched_eligible(M, K):
+    return _multi()
+
+
+def pairwise_self_batched(C_all):
+    return torch.stack([pairwise_inner(C) for C in C_all])
+
+
+def head_forward_batched(S_all, nsq_all, r0, specs, scales):
+    return torch.stack([head_forward(S, n, r0, sp, sc)[1] for S, n, sp, sc in zip(S_all, nsq_all, specs, scales)])
+
+
+def head_backward_batched(S_all, nsq_all, r0, specs, up, scales):
+    return torch.stack([head_backward(S, n, r0, sp, up, sc) for S, n, sp, sc in zip(S_all, nsq_all, specs, scales)])
+
+
+def coef_gamma_batched(A_all, cv_all):
+    return torch.stack([coef_gamma(A, c) for A, c in zip(A_all, cv_all)])
+
+
+def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag):
+    CALLS['combine_batched'] = CALLS.get('combine_batched', 0) + 1
+    return torch.stack([combine_slice(A, Cs, g, B, n_start, detach_diag) for A, Cs, g in zip(A_all, Cs_all, gamma_all)])
+
+
+def wbound_batched(A_all, nsq_all, gamma_all):
+    return torch.ones(A_all.shape[:2], dtype=torch.float64)       # (only scales the fp16 split on the GPU; unused here)
+
+
+def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
+    return _multi()
+
+
+def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
+    CALLS['bwd_multi_sliced' if slice_rows else 'bwd_multi'] = CALLS.get('bwd_multi_sliced' if slice_rows else 'bwd_multi', 0) + 1
+    out = []
+    for W, X in zip(Ws, Xs):
+        M, B = X.shape[0], X.shape[1]
+        if slice_rows:      # [B/rows, M, rows, B] as it arrived -> [M,B,B]
+            W = W.reshape(B // slice_rows, M, slice_rows, B).permute(1, 0, 2, 3).reshape(M, B, B)
+        out.append(gram_bwd_w(W.reshape(M, B, B), X))
+    return out

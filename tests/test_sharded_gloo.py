@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, cfgname, out, mode):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode,
+                      CPU_BACKEND_MULTI='1' if cfgname == 'he_sliced' else '0')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import cpu_backend
     from hyper_amd.diversity.model_kernels import build_model_kernel
@@ -27,6 +28,8 @@ def _worker(rank, world, port, cfgname, out, mode):
     kern = ShardedModelLayersKernel(build_model_kernel(cfg), backend=cpu_backend)
     loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
     loss.backward()
+    if cfgname == 'he_sliced':
+        assert cpu_backend.CALLS == {'gram_multi_sliced': 1, 'combine_batched': 1, 'bwd_multi_sliced': 1}, cpu_backend.CALLS
     torch.save({'loss': loss.detach(), 'grads': [x.grad for x in xs]}, '%s.%d' % (out, rank))
     dist.destroy_process_group()
 
@@ -34,8 +37,12 @@ def _worker(rank, world, port, cfgname, out, mode):
 def _case(name):
     torch.manual_seed(21)
     B = 5 if name == 'he_uneven' else 12      # B*B = 25 does not split evenly: slices of 12/13 and 8/8/9 elements
-    feats = [torch.randn(6, B, p, dtype=torch.float64) for p in (9, 20)]
+    M = 6
+    if name == 'he_sliced':                   # slices of whole Gram rows (4 / 2 of 8): the slice-major layouts, no repacking
+        M, B = 8, 8
+    feats = [torch.randn(M, B, p, dtype=torch.float64) for p in (9, 20)]
     lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031), 'he_uneven': dict(name='he', eps=0.0025, arc_eps=0.031),
+          'he_sliced': dict(name='he', eps=0.0025, arc_eps=0.031),
           'he_exp_dr': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True, detach_right=True),
           'cka': dict(name='cka', eps=1e-6)}[name]
     lk['feature_kernel'] = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
@@ -63,6 +70,13 @@ def test_sharded_matches_single_process_oracle(name, world, mode, tmp_path):
         for g, x in zip(res['grads'], xo):
             exp = x.grad[r * Ml:(r + 1) * Ml]
             assert np.abs(g.numpy() - exp.numpy()).max() <= 1e-9 * np.abs(exp.numpy()).max()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_slice_major_layouts_and_batched_stages_match_oracle(world, tmp_path):
+    """The branch of hyper_amd.parallel the GPU path takes when a slice is whole Gram rows: Grams produced directly in
+    the all-to-all's send order, W consumed as it arrives, one combine / bounds / dX call for all layers."""
+    test_sharded_matches_single_process_oracle('he_sliced', world, 'slice', tmp_path)
 
 
 def test_slice_bounds():
