@@ -86,13 +86,12 @@ static long long small_grid() {
 }
 
 template <bool VEC, bool AMAX>
-__global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
-                                                      float* __restrict__ sbar, unsigned* __restrict__ xmax) {
+__device__ __forceinline__ void colmean_body(const float* __restrict__ X, int B, int P, float* __restrict__ sbar,
+                                             unsigned* __restrict__ xmax, int bx, int m) {
   __shared__ f32x4 red[16][32];
   float mx = 0.f;
-  const int m = blockIdx.y;
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int p = (blockIdx.x * 32 + cx) * 4;
+  const int p = (bx * 32 + cx) * 4;
   const float* Xm = X + (size_t)m * B * P;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (p < P) {
@@ -137,6 +136,36 @@ __global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ 
     for (int e = 0; e < 4; ++e)
       if (p + e < P) sbar[(size_t)m * P + p + e] = s[e] * inv;
   }
+}
+
+template <bool VEC, bool AMAX>
+__global__ __launch_bounds__(512) void colmean_kernel(const float* __restrict__ X, int B, int P,
+                                                      float* __restrict__ sbar, unsigned* __restrict__ xmax) {
+  colmean_body<VEC, AMAX>(X, B, P, sbar, xmax, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Column means of ALL tracked layers in one launch (and one memset of their maxima): five launches and five memsets
+// per evaluation otherwise, each with its own tail.  blockIdx.x runs over the layers' 128-column blocks, deepest first.
+constexpr int kMaxColLayers = 16;
+struct ColmeanMultiArgs {
+  const float* X[kMaxColLayers];
+  float* sbar[kMaxColLayers];
+  int P[kMaxColLayers];
+  int blk_end[kMaxColLayers];
+  int L;
+};
+__global__ __launch_bounds__(512) void colmean_multi_kernel(ColmeanMultiArgs a, int B, unsigned* __restrict__ xmax_all, int M) {
+  const int b = blockIdx.x;
+  int li = 0, b0 = 0;
+  while (li + 1 < a.L && b >= a.blk_end[li]) {
+    b0 = a.blk_end[li];
+    ++li;
+  }
+  const float* X = a.X[0]; float* sbar = a.sbar[0]; int P = a.P[0];
+#pragma unroll
+  for (int i = 1; i < kMaxColLayers; ++i)
+    if (i == li) { X = a.X[i]; sbar = a.sbar[i]; P = a.P[i]; }
+  colmean_body<true, true>(X, B, P, sbar, xmax_all + (size_t)li * M, b - b0, (int)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2521,6 +2550,28 @@ int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* x
   else
     hipLaunchKernelGGL((colmean_kernel<false, false>), grid, dim3(512), 0, st, X, B, P, sbar, xm);
   return check_launch("colmean");
+}
+
+int hecka_colmean_multi_f32(int L, const float* const* X, int M, int B, const int* P, float* const* sbar, float* xmax_all,
+                            void* stream) {
+  clear_error();
+  if (L <= 0 || L > kMaxColLayers || !X || !P || !sbar || !xmax_all) return fail(HECKA_EINVAL, "colmean_multi: bad argument%s");
+  if (M <= 0 || B <= 0 || M > 65535) return fail(HECKA_EINVAL, "colmean_multi: bad size%s");
+  ColmeanMultiArgs a;
+  a.L = L;
+  long long blocks = 0;
+  for (int i = 0; i < L; ++i) {
+    if (!X[i] || !sbar[i] || P[i] <= 0 || P[i] % 4 != 0 || !aligned16(X[i]) || !aligned16(sbar[i]))
+      return fail(HECKA_EINVAL, "%scolmean_multi: layer needs P %% 4 == 0 and 16-byte alignment (P = %lld)", "", (long long)(P ? P[i] : 0));
+    blocks += (P[i] + 127) / 128;
+    a.X[i] = X[i]; a.sbar[i] = sbar[i]; a.P[i] = P[i]; a.blk_end[i] = (int)blocks;
+  }
+  for (int i = L; i < kMaxColLayers; ++i) { a.X[i] = a.X[L - 1]; a.sbar[i] = a.sbar[L - 1]; a.P[i] = a.P[L - 1]; a.blk_end[i] = (int)blocks; }
+  if (blocks > 0x7fffffffLL) return fail(HECKA_EINVAL, "colmean_multi: grid too large%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(xmax_all, 0, (size_t)L * M * sizeof(unsigned), st) != hipSuccess) return check_launch("colmean_multi (memset)");
+  hipLaunchKernelGGL(colmean_multi_kernel, dim3((unsigned)blocks, M), dim3(512), 0, st, a, B, reinterpret_cast<unsigned*>(xmax_all), M);
+  return check_launch("colmean_multi");
 }
 
 int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar, float* xmax, void* stream) {

@@ -16,6 +16,7 @@ SIGNATURES = {
     'hecka_version': (_i, []),
     'hecka_last_error': (ctypes.c_char_p, []),
     'hecka_colmean_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'hecka_colmean_multi_f32': (_i, [_i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_center_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
     'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),

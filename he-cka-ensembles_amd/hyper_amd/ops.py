@@ -246,16 +246,23 @@ def centered_gram_multi(Xs, slice_rows=0):
     out = []
     cvec_all = torch.empty((len(Xs), M, B), device=dev, dtype=torch.float32)   # one tensor: the batched gamma stage reads it whole
     C_all = torch.empty((len(Xs), M, B, B), device=dev, dtype=torch.float32)   # likewise for the batched pairwise stage
-    for li, X in enumerate(Xs):
-        P = X.shape[2]
-        sbar = torch.empty((M, P), device=dev, dtype=torch.float32)
-        xmax = torch.empty((M,), device=dev, dtype=torch.float32)
-        C = C_all[li]
-        cvec = cvec_all[li]
-        _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
-        out.append((C, cvec, xmax, sbar))
     n = len(Xs)
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
+    xmax_all = torch.empty((n, M), device=dev, dtype=torch.float32)
+    sbars = [torch.empty((M, X.shape[2]), device=dev, dtype=torch.float32) for X in Xs]
+    one_colmean = dt == 0 and all(X.shape[2] % 4 == 0 for X in Xs) and os.environ.get('HECKA_COLMEAN_MULTI', '1') != '0'
+    if one_colmean:      # every layer's column means (and maxima) in one launch, deepest layer first
+        _lib.check(L.hecka_colmean_multi_f32(n, ptrs([Xs[i] for i in order]), M, B, (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]),
+                                             ptrs([sbars[i] for i in order]), _p(xmax_all), st), 'colmean_multi')
+    for li, X in enumerate(Xs):
+        P = X.shape[2]
+        sbar = sbars[li]
+        xmax = xmax_all[order.index(li)] if one_colmean else xmax_all[li]
+        C = C_all[li]
+        cvec = cvec_all[li]
+        if not one_colmean:
+            _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
+        out.append((C, cvec, xmax, sbar))
     Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
     nbytes = L.hecka_gram_center_multi_workspace_bytes(n, M, B, Ps)     # split-K slabs when the grid would be small
     ws = torch.empty((nbytes // 4,), device=dev, dtype=torch.float32) if nbytes else None

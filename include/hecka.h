@@ -55,6 +55,10 @@ const char* hecka_last_error(void);
  * C = K - rowmean(K) == X (X - 1 sbar^T)^T, so the centring is applied to the features.
  * xmax (may be NULL): [M] side output max |X[m]| for the f16x3 GEMMs (zeroed and filled by this call). */
 int hecka_colmean_f32(const float* X, int M, int B, int P, float* sbar, float* xmax, void* stream);
+/* hecka_colmean_f32 for L layers (same M and B) in ONE launch and one memset: X / sbar HOST arrays of L device pointers, P
+ * a host array of widths (P % 4 == 0, 16-byte aligned), xmax_all [L, M] contiguous.  Same values as the per-layer call. */
+int hecka_colmean_multi_f32(int L, const float* const* X, int M, int B, const int* P, float* const* sbar, float* xmax_all,
+                            void* stream);
 
 /* Centred linear Gram of every member, written once:
  *   C[m] = X_m X_m^T - rowmean(X_m X_m^T)   ([M,B,B]),   cvec[m,b] = sbar_m . (x_b - sbar_m)  ([M,B])
