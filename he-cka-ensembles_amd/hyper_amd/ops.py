@@ -769,6 +769,11 @@ def raw_gram(X):
     zero = torch.zeros((M, P), device=X.device, dtype=torch.float32)
     G = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
     scratch = torch.empty((M, B), device=X.device, dtype=torch.float32)
+    # no maxima (xmax) on purpose: the cossim / rbf transforms divide by (or difference) each row's OWN squared norm, and
+    # the fp16 split scaled by the member's maximum loses the relative precision of rows far below it - tried: a row at
+    # 1e-6 of the maximum came out with a zero norm, NaN cosines after some training steps of the hypernetwork.  bf16x6
+    # (interior shapes) and fp32 MFMA (ragged) have no range assumption.  (Maxima passes over W and X for the dX GEMM of
+    # these layers were tried too: the two extra HBM passes cost what the faster GEMM saves at the hypernetwork's sizes.)
     _lib.check(L.hecka_gram_center_f32(_p(X), _p(zero), None, M, B, P, _p(G), _p(scratch), get_gemm_mode(), _stream()), 'gram')
     return G
 
