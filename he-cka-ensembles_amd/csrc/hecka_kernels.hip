@@ -3787,7 +3787,9 @@ int hecka_gram_bwd_multi_eligible(int L, int M, int B, const int* P, int slice_r
     wg += (long long)M * tilesM * ((P[i] + 127) / 128);
   }
   if (wg >= (1ll << 31)) return 0;
-  if (!interior && !ragged_x3_wanted(wg)) return 0;
+  // ragged shapes: one launch for L >= 2 layers pays even on a small grid (MNIST, 5 x 300: 4 layers in one Gram and one
+  // dX launch instead of 8 small fp32-MFMA launches, +4 % steps/s); a single layer keeps the grid rule
+  if (!interior && !ragged_x3_wanted(L >= 2 ? (1ll << 30) : wg)) return 0;
   return 1;
 }
 
