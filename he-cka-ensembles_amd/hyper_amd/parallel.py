@@ -197,7 +197,11 @@ class _SlicedLayers(torch.autograd.Function):
                 Ws_all = be.combine_slice_batched(A_all, ctx.Cs_all, gamma_all, B, bounds[rank], ctx.detach)
             if hasattr(be, 'wbound_batched') and all(s[7] is not None for s in ctx.saved):
                 wmax_all = be.wbound_batched(A_all[:, r0:r0 + Ml].contiguous(), nsq_all, gamma_all[:, r0:r0 + Ml].contiguous())
-        for li, (X, Cs, cv_all, S, nsq, spec, scale, xmax) in enumerate(ctx.saved):
+        # exchanges are issued deepest layer first: its W arrives first and its dX GEMM (half the flops at the bench's
+        # widths) runs while the other layers' slices are still on the links
+        order = sorted(range(len(ctx.saved)), key=lambda i: -ctx.saved[i][0].shape[2])
+        for li in order:
+            X, Cs, cv_all, S, nsq, spec, scale, xmax = ctx.saved[li]
             if ctx.batch is not None:
                 A, gamma = A_all[li], gamma_all[li]
             else:
@@ -216,13 +220,26 @@ class _SlicedLayers(torch.autograd.Function):
                 wmax = be.wbound(A[r0:r0 + Ml].contiguous(), nsq, gamma[r0:r0 + Ml].contiguous())
             pending.append((X, recv, work, wmax, xmax))
         gate = (ctx.gate,) if ctx.gate is not None else ()
+
+        def in_layer_order(grads):      # pending (and grads) are in `order`; autograd wants the layers' own order
+            out = [None] * len(grads)
+            for pos, li in enumerate(order):
+                out[li] = grads[pos]
+            return (None,) + tuple(out)
         if ctx.sliced and be.gram_bwd_multi_eligible([p[1] for p in pending], [p[0] for p in pending], [p[3] for p in pending],
                                                       [p[4] for p in pending], ctx.sliced):
-            for p in pending:
-                p[2].wait()
-            # W stays as it arrived, [G, Ml, rows, B]: ONE dX launch for all layers reads it in that order
-            return (None,) + tuple(be.gram_bwd_multi([p[1] for p in pending], [p[0] for p in pending], [p[3] for p in pending],
-                                                     [p[4] for p in pending], *gate, slice_rows=ctx.sliced))
+            # W stays as it arrived, [G, Ml, rows, B]: the dX launches read it in that order.  Two launches when there is
+            # an exchange to hide: the deepest layer as soon as its slices are in, the rest in one launch behind it
+            cut = 1 if (world > 1 and len(pending) >= 3 and os.environ.get('HECKA_SHARD_BWD_SPLIT', '1') != '0') else len(pending)
+            grads = []
+            for part in (pending[:cut], pending[cut:]):
+                if not part:
+                    continue
+                for p in part:
+                    p[2].wait()
+                grads += be.gram_bwd_multi([p[1] for p in part], [p[0] for p in part], [p[3] for p in part],
+                                           [p[4] for p in part], *gate, slice_rows=ctx.sliced)      # (one layer is a valid launch)
+            return in_layer_order(grads)
         Wl = []
         for X, recv, work, wmax, xmax in pending:
             work.wait()
@@ -239,10 +256,9 @@ class _SlicedLayers(torch.autograd.Function):
             Wl.append(W.view(Ml, B, B))
         multi = getattr(be, 'gram_bwd_multi_eligible', None)
         if multi is not None and multi(Wl, [p[0] for p in pending], [p[3] for p in pending], [p[4] for p in pending]):
-            return (None,) + tuple(be.gram_bwd_multi(Wl, [p[0] for p in pending], [p[3] for p in pending],
-                                                     [p[4] for p in pending], *gate))
-        grads = [be.gram_bwd_w(W, X, wmax, xmax, *gate) for W, (X, _, _, wmax, xmax) in zip(Wl, pending)]
-        return (None,) + tuple(grads)
+            return in_layer_order(be.gram_bwd_multi(Wl, [p[0] for p in pending], [p[3] for p in pending],
+                                                    [p[4] for p in pending], *gate))
+        return in_layer_order([be.gram_bwd_w(W, X, wmax, xmax, *gate) for W, (X, _, _, wmax, xmax) in zip(Wl, pending)])
 
 
 class _GatheredLayers(torch.autograd.Function):

@@ -29,7 +29,8 @@ def _worker(rank, world, port, cfgname, out, mode):
     loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
     loss.backward()
     if cfgname == 'he_sliced':
-        assert cpu_backend.CALLS == {'gram_multi_sliced': 1, 'combine_batched': 1, 'bwd_multi_sliced': 1}, cpu_backend.CALLS
+        # (three layers: the deepest one's dX as soon as its slices are in, the other two in one call behind it)
+        assert cpu_backend.CALLS == {'gram_multi_sliced': 1, 'combine_batched': 1, 'bwd_multi_sliced': 2}, cpu_backend.CALLS
     torch.save({'loss': loss.detach(), 'grads': [x.grad for x in xs]}, '%s.%d' % (out, rank))
     dist.destroy_process_group()
 
@@ -40,14 +41,14 @@ def _case(name):
     M = 6
     if name == 'he_sliced':                   # slices of whole Gram rows (4 / 2 of 8): the slice-major layouts, no repacking
         M, B = 8, 8
-    feats = [torch.randn(M, B, p, dtype=torch.float64) for p in (9, 20)]
+    feats = [torch.randn(M, B, p, dtype=torch.float64) for p in ((9, 20, 14) if name == 'he_sliced' else (9, 20))]
     lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031), 'he_uneven': dict(name='he', eps=0.0025, arc_eps=0.031),
           'he_sliced': dict(name='he', eps=0.0025, arc_eps=0.031),
           'he_exp_dr': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True, detach_right=True),
           'cka': dict(name='cka', eps=1e-6)}[name]
     lk['feature_kernel'] = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
     cfg = {'name': 'model_layers', 'layer_kernel': lk, 'reduction': 'mean',
-           'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2]}}
+           'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2, 0.7][:len(feats)]}}
     return cfg, feats
 
 
