@@ -138,8 +138,13 @@ struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constan
 // term (16-bit features times a power of two), so B has no low plane and the product list is hh + lh.
 // ALOW = false: the same for A (both false: one product, hh).
 template <int TM, int TN, bool NN, class Pro, int SCHEME = 0, bool FOLD = true, int EA = kElemF32, int EB = kElemF32,
-          bool BLOW = true, bool ALOW = true, bool SAMEAB = false, bool RAGGED = false, bool ASLICED = false>
+          bool BLOW = true, bool ALOW = true, bool SAMEAB = false, bool RAGGED = false, bool ASLICED = false, int NT = kThreads>
 struct GemmTileX6 {
+  // NT threads: 256 (four waves, 2 x 2) or 512 (eight waves, 2 x 4, with TN = 256: a 256 x 256 tile stages a third
+  // fewer operand bytes per flop than two 256 x 128 tiles and half the transposing gathers)
+  static_assert(NT == 2 * TN, "one thread per column and k-half of the NN operand: NT = 2 TN");
+  static constexpr int RPP = NT / 4;            // rows of a k-contiguous operand staged per pass
+  static constexpr int WCOLS = NT / 128;        // wave grid: 2 rows x WCOLS columns
   // ASLICED: the rows of A lie in blocks of 2^a_rshift rows, block b of this member at element offset b * a_blk (the
   // member-sharded path keeps W in the order the all-to-all delivers it: [slice, member, rows of the slice, B])
   static_assert(!RAGGED || (!implicit_b<Pro>::value && !implicit_nt<Pro>::value), "ragged tiles: explicit operands only");
@@ -150,8 +155,8 @@ struct GemmTileX6 {
   static_assert((BLOW && ALOW) || SCHEME == 1, "single-plane operands: f16x3 only");
   static constexpr int SA = elem_bytes<EA>(), SB = elem_bytes<EB>();
   static constexpr int NP = SCHEME == 1 ? 2 : 3;
-  static constexpr int WM = TM / 2, WN = TN / 2, MI = WM / 32, NI = WN / 32;
-  static constexpr int CA = TM * 4 / kThreads, CB = TN * 4 / kThreads;  // 4-k quads staged per thread per tile
+  static constexpr int WM = TM / 2, WN = TN / (NT / 128), MI = WM / 32, NI = WN / 32;
+  static constexpr int CA = TM * 4 / NT, CB = TN * 4 / NT;  // 4-k quads staged per thread per tile
   static_assert(CA >= 1 && CB >= 1, "tile too small");
   using Smem = X6Smem<TM, TN, NP>;
   f32x16 acc[MI][NI];
@@ -161,7 +166,7 @@ struct GemmTileX6 {
                                       unsigned bytesB, int ldb, int row0, int col0, int kbeg, int kend, Pro& pro,
                                       int a_rshift = 31, unsigned a_blk = 0) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wr = wave / (NT / 128), wc = wave % (NT / 128), l31 = lane & 31, h = lane >> 5;
     f32x16 loc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -183,15 +188,15 @@ struct GemmTileX6 {
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       if (ASLICED) {
-        const unsigned r = (unsigned)(row0 + srow + 64 * i);
+        const unsigned r = (unsigned)(row0 + srow + RPP * i);
         aoff[i] = ((r >> a_rshift) * a_blk + (r & ((1u << a_rshift) - 1u)) * lda + 4 * kq) * (unsigned)SA;
       } else {
-        aoff[i] = ((unsigned)(srow + 64 * i) * lda + 4 * kq) * (unsigned)SA;
+        aoff[i] = ((unsigned)(srow + RPP * i) * lda + 4 * kq) * (unsigned)SA;
       }
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i)
-      bgoff[i] = (NN ? (unsigned)(8 * (t >> 7) + 4 * i) * ldb + (t & 127) : (unsigned)(srow + 64 * i) * ldb + 4 * kq) *
+      bgoff[i] = (NN ? (unsigned)(8 * (t / TN) + 4 * i) * ldb + (t % TN) : (unsigned)(srow + RPP * i) * ldb + 4 * kq) *
                  (unsigned)SB;
     const int klen = kend - kbeg;
     const int ntiles = RAGGED ? (klen + kX6BK - 1) / kX6BK : klen / kX6BK;
@@ -231,14 +236,14 @@ struct GemmTileX6 {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if constexpr (implicit_b<Pro>::value) {
-              const int k = __builtin_amdgcn_readfirstlane(kbeg + kt * kX6BK + 8 * (t >> 7) + 4 * i + c);   // wave-uniform
+              const int k = __builtin_amdgcn_readfirstlane(kbeg + kt * kX6BK + 8 * (t / TN) + 4 * i + c);   // wave-uniform
               rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)pro.bvoff(k), 0, 0));
               continue;
             }
             int so = (int)(sB0 + (unsigned)(kt * kX6BK + c) * ldb * (unsigned)SB);
             unsigned vo = bgoff[i];
             if (RAGGED) {
-              vo = kt * kX6BK + 8 * (t >> 7) + 4 * i + c < klen ? bgoff[i] + (unsigned)so : kOOB;
+              vo = kt * kX6BK + 8 * (t / TN) + 4 * i + c < klen ? bgoff[i] + (unsigned)so : kOOB;
               so = 0;
             }
             if (EB == kElemF32)
@@ -271,7 +276,7 @@ struct GemmTileX6 {
     const int soff = srow * kX6LD + 4 * kq;
     int boff[CB];
 #pragma unroll
-    for (int i = 0; i < CB; ++i) boff[i] = NN ? (t & 127) * kX6LD + 8 * (t >> 7) + 4 * i : soff + 64 * i * kX6LD;
+    for (int i = 0; i < CB; ++i) boff[i] = NN ? (t % TN) * kX6LD + 8 * (t / TN) + 4 * i : soff + RPP * i * kX6LD;
     auto stage_a = [&](auto SET, int st) __attribute__((always_inline)) {   // split + LDS write of the A quads
       constexpr int S = decltype(SET)::value;
 #pragma unroll
@@ -287,7 +292,7 @@ struct GemmTileX6 {
           split2(ra[S][i], 2, p[0], p[1], p[2], 1);
         }
 #pragma unroll
-        for (int q = 0; q < (ALOW ? NP : 1); ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + 64 * i * kX6LD]) = p[q];
+        for (int q = 0; q < (ALOW ? NP : 1); ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][soff + RPP * i * kX6LD]) = p[q];
       }
     };
     auto stage_b = [&](auto SET, int st) __attribute__((always_inline)) {
@@ -325,7 +330,7 @@ struct GemmTileX6 {
     // or the loads of one operand: about one 32-cycle MFMA).  FIRST: the local chain starts from zero.  GUARD: tail tiles, where
     // tile kt+1 / kt+3 may not exist; the steady-state instance has no branch inside.
     static_assert(SCHEME == 1 || (TM == 128 && TN == 128), "the bf16x6 schedule is written for the 128x128 tile");
-    static_assert((TM == 256 || TM == 128 || TM == 64) && TN == 128, "tile: 256, 128 or 64 rows by 128 columns");
+    static_assert((TM == 256 || TM == 128 || TM == 64) && (TN == 128 || (TN == 256 && TM == 256)), "tile: 256, 128 or 64 rows by 128 columns, or 256 x 256");
     auto iter = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
       constexpr int S = decltype(NSET)::value;
       constexpr bool G = decltype(GUARD)::value;
@@ -385,7 +390,7 @@ struct GemmTileX6 {
             } else {
 #pragma unroll
               for (int q = 0; q < 3; ++q) {
-                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q];
+                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + RPP * quad * kX6LD]) = qv[q];
                 else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
               }
             }
@@ -458,7 +463,7 @@ struct GemmTileX6 {
             } else {
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                if (isA) { if (q == 0 || ALOW) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + 64 * quad * kX6LD]) = qv[q]; }
+                if (isA) { if (q == 0 || ALOW) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + RPP * quad * kX6LD]) = qv[q]; }
                 else if (q == 0 || BLOW) *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
               }
             }
@@ -503,7 +508,7 @@ struct GemmTileX6 {
   template <class Fn>
   __device__ __forceinline__ void for_each(Fn&& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wr = wave / (NT / 128), wc = wave % (NT / 128), l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll

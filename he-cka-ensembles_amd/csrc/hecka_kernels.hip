@@ -1052,21 +1052,21 @@ struct ScaleProX6 {
 // TM = 256 (no local chains only): each wave owns 128 x 64 of a 256 x 128 tile - a staged X tile feeds twice the MFMAs
 // (24 per k-tile per wave behind one barrier), fragment reads and staging work per MFMA fall by a quarter; two
 // workgroups per CU (128 accumulator registers per lane).
-template <int SCHEME, bool FOLD, int EX, int TM, bool RAGGED, bool SLICED>
+template <int SCHEME, bool FOLD, int EX, int TM, bool RAGGED, bool SLICED, int TN = 128>
 __device__ __forceinline__ void gram_bwd_x6_body(const float* __restrict__ W, const void* __restrict__ X,
                                                  const unsigned* __restrict__ wmax, const float* __restrict__ xmax,
                                                  void* __restrict__ dX, int B, int P, int tilesM, int tilesN, int xcd_map,
                                                  const float* __restrict__ gate, int w, int M, int slice_rshift) {
   static_assert(TM == 128 || !FOLD, "the 256-row tile has no registers for local chains");
-  using Tile = GemmTileX6<TM, 128, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED, SLICED>;
+  using Tile = GemmTileX6<TM, TN, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED, SLICED, 2 * TN>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
   member_tile_w(w, tilesM * tilesN, xcd_map, m, tl);
   const int ti = tl % tilesM, tj = tl / tilesM;
   if (gate && *gate == 0.f) {
-    if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * 128, B, P, TM, 128);
-    else zero_tile(static_cast<unsigned short*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * 128, B, P, TM, 128);
+    if (EX == kElemF32) zero_tile(static_cast<float*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * TN, B, P, TM, TN);
+    else zero_tile(static_cast<unsigned short*>(dX) + (size_t)m * B * P, (size_t)P, ti * TM, tj * TN, B, P, TM, TN);
     return;
   }
   ScaleProX6<SCHEME> pro;
@@ -1079,14 +1079,14 @@ __device__ __forceinline__ void gram_bwd_x6_body(const float* __restrict__ W, co
     const unsigned rpg = 1u << slice_rshift, blk = (unsigned)M * rpg * B;
     const unsigned bytesW = (((unsigned)B >> slice_rshift) - 1u) * blk * 4u + rpg * B * 4u;
     tile.run(sm, W + (size_t)m * rpg * B, bytesW, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
-             (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro, slice_rshift, blk);
+             (unsigned)B * P * ES, P, ti * TM, tj * TN, 0, B, pro, slice_rshift, blk);
   } else {
     tile.run(sm, W + (size_t)m * B * B, (unsigned)B * B * 4u, B, static_cast<const char*>(X) + (size_t)m * B * P * ES,
-             (unsigned)B * P * ES, P, ti * TM, tj * 128, 0, B, pro);
+             (unsigned)B * P * ES, P, ti * TM, tj * TN, 0, B, pro);
   }
   tile.for_each([&](int lr, int lc, float v) {
-    if (RAGGED && (ti * TM + lr >= B || tj * 128 + lc >= P)) return;
-    const size_t idx = (size_t)m * B * P + (size_t)(ti * TM + lr) * P + tj * 128 + lc;
+    if (RAGGED && (ti * TM + lr >= B || tj * TN + lc >= P)) return;
+    const size_t idx = (size_t)m * B * P + (size_t)(ti * TM + lr) * P + tj * TN + lc;
     const float r = SCHEME == 1 ? v * unscale : v;
     if (EX == kElemF32) static_cast<float*>(dX)[idx] = r;
     else if (EX == kElemBF16) static_cast<__bf16*>(dX)[idx] = (__bf16)r;
@@ -1121,8 +1121,8 @@ struct BwdMultiArgs {
   int L, M;
 };
 
-template <int TM, bool RAGGED, bool SLICED>
-__global__ __launch_bounds__(kThreads, TM == 256 ? 2 : 3) void gram_bwd_x6_multi_kernel(BwdMultiArgs a, int B, int tilesM, int xcd_map,
+template <int TM, bool RAGGED, bool SLICED, int TN = 128>
+__global__ __launch_bounds__(2 * TN, TN == 256 ? 1 : (TM == 256 ? 2 : 3)) void gram_bwd_x6_multi_kernel(BwdMultiArgs a, int B, int tilesM, int xcd_map,
                                                                                        const float* __restrict__ gate,
                                                                                        int slice_rshift) {
   const int w = blockIdx.x;
@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(kThreads, TM == 256 ? 2 : 3) void gram_bwd_x6_multi
 #pragma unroll
   for (int i = 1; i < kMaxGramLayers; ++i)
     if (i == li) { W = a.l[i].W; X = a.l[i].X; wmax = a.l[i].wmax; xmax = a.l[i].xmax; dX = a.l[i].dX; P = a.l[i].P; }
-  gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED>(W, X, wmax, xmax, dX, B, P, tilesM, (P + 127) / 128, xcd_map, gate,
-                                                          w - w0, a.M, slice_rshift);
+  gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED, TN>(W, X, wmax, xmax, dX, B, P, tilesM, (P + TN - 1) / TN, xcd_map, gate,
+                                                              w - w0, a.M, slice_rshift);
 }
 
 // General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
@@ -2529,6 +2529,12 @@ static inline bool pairwise_x6() {
   return e && atoi(e) != 0;
 }
 
+// HECKA_BWD_TN: column width of the multi-layer dX tile (128: four waves; 256: eight waves, one workgroup per CU)
+static inline int bwd_tn() {
+  const char* e = getenv("HECKA_BWD_TN");
+  return e ? atoi(e) : 256;
+}
+
 static inline bool gemm_mode_ok(int mode) {
   return mode == HECKA_GEMM_AUTO || mode == HECKA_GEMM_FP32 || mode == HECKA_GEMM_BF16X6;
 }
@@ -3807,6 +3813,10 @@ int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X
   bool interior = B % 128 == 0;
   for (int i = 0; i < L; ++i) interior = interior && P[i] % 128 == 0;
   const int tm = (interior && B % 256 == 0) ? 256 : 128, tilesM = (B + tm - 1) / tm;
+  // 256 x 256 tile on eight waves (one workgroup per CU): every layer a multiple of 256 wide
+  bool wide = tm == 256 && bwd_tn() == 256;
+  for (int i = 0; i < L; ++i) wide = wide && P[i] % 256 == 0;
+  const int tn = wide ? 256 : 128;
   BwdMultiArgs a;
   a.L = L;
   a.M = M;
@@ -3814,7 +3824,7 @@ int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X
   for (int i = 0; i < L; ++i) {
     if (!W[i] || !X[i] || !wmax[i] || !xmax[i] || !dX[i]) return fail(HECKA_EINVAL, "gram_bwd_multi: null layer pointer%s");
     if (!aligned16(W[i]) || !aligned16(X[i])) return fail(HECKA_EINVAL, "gram_bwd_multi: needs 16-byte alignment%s");
-    wg += (long long)M * tilesM * ((P[i] + 127) / 128);
+    wg += (long long)M * tilesM * ((P[i] + tn - 1) / tn);
     a.l[i] = BwdLayerArgs{W[i], X[i], reinterpret_cast<const unsigned*>(wmax[i]), xmax[i], dX[i], P[i], (int)wg};
   }
   for (int i = L; i < kMaxGramLayers; ++i) a.l[i] = a.l[L - 1];
@@ -3822,7 +3832,12 @@ int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X
   const int xcd = (int)(M % 8 == 0), rs = slice_rows ? slice_shift(B, slice_rows) : 31;
 #define HECKA_BWDM(TMV, RAG, SL) \
   hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<TMV, RAG, SL>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, tilesM, xcd, gate, rs)
-  if (slice_rows) {
+  if (wide) {
+    if (slice_rows)
+      hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, true, 256>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
+    else
+      hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, false, 256>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
+  } else if (slice_rows) {
     if (tm == 256) HECKA_BWDM(256, false, true);
     else if (interior) HECKA_BWDM(128, false, true);
     else HECKA_BWDM(128, true, true);

@@ -411,8 +411,10 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
         PROFILE['gram_bwd'].append((e0, e1, sum(2.0 * M * B * B * X.shape[2] for X in Xs)))
         global LAST_BWD_KERNEL
         interior = B % 128 == 0 and all(X.shape[2] % 128 == 0 for X in Xs)
-        LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s>' % (256 if interior and B % 256 == 0 else 128,
-                                                                     'false' if interior else 'true', 'true' if slice_rows else 'false')
+        tm = 256 if interior and B % 256 == 0 else 128
+        wide = tm == 256 and all(X.shape[2] % 256 == 0 for X in Xs) and os.environ.get('HECKA_BWD_TN', '256') == '256'
+        LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s, %d>' % (tm, 'false' if interior else 'true',
+                                                                         'true' if slice_rows else 'false', 256 if wide else 128)
     _GemmChain.leave(Xs[0].device, chain)
     return dXs
 
