@@ -51,6 +51,7 @@ def test_combine_slice_equals_full_combine(M, B):
 
 
 @pytest.mark.parametrize('M,B,Ps,rows', [(8, 512, (2048, 512, 128), 64), (16, 128, (256, 128), 32), (64, 512, (1024, 512), 0),
+                                          (8, 512, (1024, 256), 64), (16, 256, (512, 256), 0),      # every layer % 256: the 256 x 256 eight-wave tile
                                           (8, 256, (384, 128), 128), (128, 400, (256, 864), 0), (8, 384, (256, 128), 0)])
 def test_multi_layer_dx_and_slice_major_layouts_are_bit_equal(M, B, Ps, rows, monkeypatch):
     """ONE dX launch for all layers (hecka_gram_bwd_multi_f32) == the per-layer launches, bit for bit (same tile code,
