@@ -30,6 +30,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kX6BK = 16;
 constexpr int kX6LD = 24;   // bf16 per padded LDS row (48 B)
 constexpr int kX6Fold = 4;  // k-tiles per local accumulation chain
+#ifndef HECKA_X3_LATE_L
+#define HECKA_X3_LATE_L 1
+#endif
 
 // SCHEME 0 "bf16x6": three bf16 planes, six products.  SCHEME 1 "f16x3": x*2^e = h + l with two fp16 terms
 // (22 significand bits), three products hh + hl + lh; half the MFMA work and 2/3 of the LDS traffic, but the
@@ -413,18 +416,25 @@ struct GemmTileX6 {
       const bool more = !G || kt + 1 < ntiles;
       const bool load = !G || kt + 3 < ntiles;
       f16x8 fa[MI][2], fb[NI][2];
+      auto rd_a = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if (p == 0 || ALOW) {
+        for (int i = 0; i < MI; ++i)
+          fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+      };
+      auto rd_b = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
-            fa[i][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
-        }
-        if (p == 0 || BLOW) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            fb[j][p] = *reinterpret_cast<const f16x8*>(&smb[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
-        }
+        for (int j = 0; j < NI; ++j)
+          fb[j][p] = *reinterpret_cast<const f16x8*>(&smb[st][p][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+      };
+      // HECKA_X3_LATE_L: only the high planes are read before the first MFMA; the low planes (first used by the second
+      // and third product group) are read in the first two MFMA gaps - half the fragment-read burst at the top of the
+      // k-tile overlaps the hh products
+      constexpr bool LATE = HECKA_X3_LATE_L && (MI * NI >= 4);
+      rd_b(0);      // (B first: the first MFMA then waits for NI + 1 reads, not MI + NI)
+      rd_a(0);
+      if (!LATE) {
+        if (ALOW) rd_a(1);
+        if (BLOW) rd_b(1);
       }
       __builtin_amdgcn_sched_barrier(0);
       constexpr int PA[3] = {0, 0, 1};
@@ -448,6 +458,8 @@ struct GemmTileX6 {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (LATE && n == 0 && BLOW) rd_b(1);
+        if (LATE && n == 1 && ALOW) rd_a(1);
         if (n == 2 * CA) { if (load) gload_a(NSET, kt + 3); }
         else if (n == 2 * CA + 1 + 2 * CB) { if (load) gload_b(NSET, kt + 3); }
         else if (n < NITEMS) {
