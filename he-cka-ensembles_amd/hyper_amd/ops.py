@@ -358,6 +358,9 @@ def wbound(A, nsq, gamma):
 def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
     """dX [Ma,B,P] = W [Ma,B,B] X   (gate: one-element fp32 device tensor, 0 = write zeros; see grad_gate)."""
     Ma, B, P = X.shape
+    if (X.dtype == torch.float32 and B % 256 == 0 and P % 256 == 0 and wmax is not None and xmax is not None
+            and gram_bwd_multi_eligible([W], [X], [wmax], [xmax])):
+        return gram_bwd_multi([W], [X], [wmax], [xmax], gate)[0]      # one layer on the 256 x 256 eight-wave tile
     dX = torch.empty_like(X)
     chain = _GemmChain.enter(X.device)
     if PROFILE is not None:
@@ -379,7 +382,7 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
 def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
     """Every layer's dX = W X in ONE launch (hecka_gram_bwd_multi_f32): fp32 features, f16x3 mode with all maxima."""
     import ctypes
-    if not 2 <= len(Xs) <= 16 or get_gemm_mode() != 0 or os.environ.get('HECKA_BWD_MULTI', '1') == '0':
+    if not 1 <= len(Xs) <= 16 or get_gemm_mode() != 0 or os.environ.get('HECKA_BWD_MULTI', '1') == '0':
         return False
     if any(w is None for w in wmaxs) or any(x is None for x in xmaxs):
         return False

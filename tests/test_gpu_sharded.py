@@ -68,7 +68,9 @@ def test_multi_layer_dx_and_slice_major_layouts_are_bit_equal(M, B, Ps, rows, mo
     wmaxs = [W.abs().amax(dim=(1, 2)) for W in Ws]
     xmaxs = [X.abs().amax(dim=(1, 2)) for X in Xs]
     assert ops.gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs)
+    monkeypatch.setenv('HECKA_BWD_MULTI', '0')       # per-layer launches on the four-wave tiles ...
     one = [ops.gram_bwd_w(W, X, wm, xm) for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)]
+    monkeypatch.delenv('HECKA_BWD_MULTI')            # ... against one launch (256 x 256 eight-wave tiles where every P % 256 == 0)
     many = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)
     for a, b in zip(one, many):
         assert torch.equal(a, b)
