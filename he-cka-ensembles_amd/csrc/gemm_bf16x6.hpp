@@ -33,6 +33,9 @@ constexpr int kX6Fold = 4;  // k-tiles per local accumulation chain
 #ifndef HECKA_X3_LATE_L
 #define HECKA_X3_LATE_L 1
 #endif
+#ifndef HECKA_X3_PREFETCH
+#define HECKA_X3_PREFETCH 1
+#endif
 
 // SCHEME 0 "bf16x6": three bf16 planes, six products.  SCHEME 1 "f16x3": x*2^e = h + l with two fp16 terms
 // (22 significand bits), three products hh + hl + lh; half the MFMA work and 2/3 of the LDS traffic, but the
@@ -327,6 +330,22 @@ struct GemmTileX6 {
     stage_b(S0{}, 0);
     if (ntiles > 2) { gload_a(S0{}, 2); gload_b(S0{}, 2); }
     __syncthreads();
+    // PREF (f16x3, both operands with two planes, at least four MFMA blocks per wave): the fragments live across k-tiles.
+    // A.h sits in slot 0 and A.l in slot 1; B.h alternates between slot (kt & 1) and B.l takes the other one.  The high
+    // planes of tile kt + 1 are read during the LAST product group of tile kt (into the registers of A.h and B.l, dead by
+    // then), behind a barrier that sits in the middle of the k-tile instead of at its end: no wave starts a k-tile by
+    // waiting for LDS, and the eight waves of a one-workgroup-per-CU tile no longer hit the LDS together.
+    constexpr bool PREF = HECKA_X3_PREFETCH && SCHEME == 1 && ALOW && BLOW && (MI * NI >= 4) &&
+                          !(TM == 256 && TN == 128);   // (the four-wave 256-row tile has no registers to spare: it would spill)
+    f16x8 pfa[PREF ? MI : 1][2], pfb[PREF ? NI : 1][2];
+    if constexpr (PREF) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        pfb[j][0] = *reinterpret_cast<const f16x8*>(&smb[0][0][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        pfa[i][0] = *reinterpret_cast<const f16x8*>(&sm.a[0][0][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+    }
 
     // one k-tile: the 24 MFMAs of tile kt (LDS stage kt & 1), with the split + LDS write of tile kt+1 (register set
     // NSET) and the global loads of tile kt+3 spread one piece per MFMA gap (a piece = 10 VALU, three ds_write_b64
@@ -485,6 +504,79 @@ struct GemmTileX6 {
       }
       __syncthreads();
     };
+    auto iter16p = [&](auto FIRST, auto NSET, auto GUARD, int kt) __attribute__((always_inline)) {
+      constexpr int S = decltype(NSET)::value;
+      constexpr bool G = decltype(GUARD)::value;
+      constexpr int NM = 3 * MI * NI, NITEMS = 2 * CA + 1 + 2 * CB + 1;
+      constexpr int BH = S == 1 ? 0 : 1, BL = 1 - BH;      // NSET is S1 on even k-tiles: B.h in slot kt & 1
+      constexpr int BAR = (2 * MI * NI - 1 > NITEMS - 1) ? 2 * MI * NI - 1 : NITEMS - 1;   // gap that holds the barrier
+      constexpr int NG = (NM > BAR + 3) ? NM : BAR + 3;
+      const int st = kt & 1;
+      const bool more = !G || kt + 1 < ntiles;
+      const bool load = !G || kt + 3 < ntiles;
+      u32x2 qv[2];
+#pragma unroll
+      for (int n = 0; n < NG; ++n) {
+        if (n < NM) {
+          const int e = n / (MI * NI), i = (n % (MI * NI)) / NI, j = n % NI;
+          const f16x8 av = pfa[i][e == 2 ? 1 : 0], bv = pfb[j][e == 1 ? BL : BH];   // hh, A.h x B.l, A.l x B.h
+          if (FOLD) {
+            f32x16 c = loc[i][j];
+            if (decltype(FIRST)::value && e == 0) {
+#pragma unroll
+              for (int q = 0; q < 16; ++q) c[q] = 0.f;
+            }
+            loc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (n == 0) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            pfb[j][BL] = *reinterpret_cast<const f16x8*>(&smb[st][1][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+        }
+        if (n == 1) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            pfa[i][1] = *reinterpret_cast<const f16x8*>(&sm.a[st][1][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+        }
+        if (n == 2 * CA) { if (load) gload_a(NSET, kt + 3); }
+        else if (n == 2 * CA + 1 + 2 * CB) { if (load) gload_b(NSET, kt + 3); }
+        else if (n < NITEMS) {
+          const bool isA = n < 2 * CA;
+          const int r = isA ? n : n - (2 * CA + 1), quad = r >> 1, step = r & 1;
+          f32x4& src = isA ? ra[S][quad] : rb[S][quad];
+          if (more && (isA || !SAMEAB)) {
+            if (step == 0) {
+              if (isA) { widen_quad<EA, false>(src); pro.stageA(NSET, src, quad); }
+              else { widen_quad<EB, NN>(src); pro.stageB(NSET, src, quad); }
+              split2h(src, 0, qv[0], qv[1], 0);
+              split2h(src, 2, qv[0], qv[1], 1);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                if (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][soff + RPP * quad * kX6LD]) = qv[q];
+                else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][boff[quad]]) = qv[q];
+              }
+            }
+          }
+        }
+        if (n == BAR) __syncthreads();      // tile kt + 1 is complete in stage st ^ 1; stage st has no reader left
+        if (n == BAR + 1 && more) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            pfb[j][BL] = *reinterpret_cast<const f16x8*>(&smb[st ^ 1][0][(wc * WN + j * 32 + l31) * kX6LD + 8 * h]);
+        }
+        if (n == BAR + 2 && more) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            pfa[i][0] = *reinterpret_cast<const f16x8*>(&sm.a[st ^ 1][0][(wr * WM + i * 32 + l31) * kX6LD + 8 * h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     auto fold = [&]() __attribute__((always_inline)) {
       if (!FOLD) return;
 #pragma unroll
@@ -497,7 +589,8 @@ struct GemmTileX6 {
     std::true_type T;
     std::false_type F;
     auto step = [&](auto FIRST, auto NSET, auto GUARD, int kt_) __attribute__((always_inline)) {
-      if constexpr (SCHEME == 1) iter16(FIRST, NSET, GUARD, kt_);
+      if constexpr (PREF) iter16p(FIRST, NSET, GUARD, kt_);
+      else if constexpr (SCHEME == 1) iter16(FIRST, NSET, GUARD, kt_);
       else iter(FIRST, NSET, GUARD, kt_);
     };
     int kt = 0;
