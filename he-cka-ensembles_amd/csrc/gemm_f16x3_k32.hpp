@@ -1,0 +1,318 @@
+// f16x3 product tile on v_mfma_f32_16x16x32_f16 (fp32 operands, interior shapes).
+//
+// The same arithmetic as GemmTileX6's SCHEME 1 (x 2^e = h + l in two fp16 terms, products hh + hl + lh accumulated in fp32,
+// local chains of 64 k folded with v_add_f32), on the OTHER f16 MFMA shape: a 32-deep k-tile feeds 16 x 16 x 32 MFMAs.  Per
+// flop the two shapes take the same cycles; under load the chip holds a higher clock on this one (MI355X_MICROARCH.md, DVFS
+// give-back item 7) - measured here before writing it: a timing proxy of the Gram kernel with two 16x16x32 per 32x32x16 ran
+// 13 % faster, the whole evaluation 5.8 %.
+//
+// Layout: LDS rows are the 32 fp16 of a k-tile (64 B, no padding); the four 16-byte chunks of row r sit at chunk ^ ((r >> 2) & 3),
+// so the 16 rows of a fragment read (ds_read_b128: lane = row, lane group = chunk) spread over all 64 banks.  Two stages x
+// two planes: (TM + TN) x 256 B - 64 KB for the 128 x 128 tile (two workgroups per CU), 128 KB for 256 x 256 (one).
+// Staging: eight lanes load the 128 bytes of one row's k-tile - whole cache lines (GemmTileX6's 16-deep tiles take a line in
+// two halves, a k-tile apart: with the lines of 2 x 256 rows in flight per CU the second half rarely still sits in the
+// L1, and the ablation builds (HECKA_ABL) showed the Gram kernel bound by its load path, not by the MFMAs).  An NN operand
+// is gathered column-wise, 16 k (one half of the tile) at a time.
+//
+// Schedule of one k-tile (per wave: MI row blocks x NI column blocks of 16 x 16, 3 MI NI MFMAs of 16 cycles):
+//   * all B fragments stay in registers for the tile, A fragments are streamed one row block ahead (two buffers);
+//   * the staging of tile kt + 1 (split + LDS write per quad, then the global loads of tile kt + 2 into the registers just
+//     freed) goes one item per STRIDE MFMA gaps;
+//   * the ONE barrier sits before the last two product groups of the last row block; behind it that block's remaining
+//     MFMAs cover the reads of tile kt + 1's first fragments (B.h into the registers of B.l, dead by then; A block 0 into
+//     the idle A buffer), so no wave starts a k-tile waiting for LDS.
+#pragma once
+#include <utility>
+#include "gemm_bf16x6.hpp"
+
+namespace hecka {
+
+constexpr int kH32BK = 32;
+// Diagnostic builds only (csrc/lab, wrong results on purpose): HECKA_ABL removes one part of the k-tile loop to see what it
+// costs - 1: the global loads, 2: split + LDS writes, 4: the barrier, 8: the fragment reads, 16: the MFMAs.
+#ifndef HECKA_ABL
+#define HECKA_ABL 0
+#endif
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int TM, int TN>
+struct H32Smem {
+  alignas(16) unsigned short a[2][2][TM * 32];   // [stage][plane h / l][row * 32 + swizzled k]
+  alignas(16) unsigned short b[2][2][TN * 32];
+};
+
+// A [rows, K] (k contiguous); NN = false: B [cols, K]; NN = true: B [K, cols].  rows / cols multiples of the tile,
+// kend - kbeg a multiple of 32, 16-byte aligned rows.  SAMEAB / ASLICED / NT as in GemmTileX6.
+// Pro: prefetch(SET, k) once per k-tile, a whole k-tile before its values are staged (SET = the tile's parity; k = the
+// first of the four k this thread stages of a k-contiguous operand), stageA(SET, quad, i) / stageB(SET, quad, i) on
+// the staged fp32 values (i: the thread's i-th row of the tile).
+template <int TM, int TN, bool NN, class Pro, bool FOLD = true, bool SAMEAB = false, bool ASLICED = false, int NT = kThreads>
+struct GemmTileH32 {
+  static_assert(NT == 2 * TN && (NT == 256 || NT == 512), "one thread per column and k-half of the NN operand");
+  static_assert(!SAMEAB || (!NN && TM == TN), "SAMEAB: NT product with a square tile");
+  static constexpr int RPK = NT / 8;            // rows of a k-contiguous operand staged per pass (8 lanes: one 128-byte row)
+  static constexpr int WCOLS = NT / 128;
+  static constexpr int WM = TM / 2, WN = TN / WCOLS, MI = WM / 16, NI = WN / 16;
+  static constexpr int CA = TM * 8 / NT;        // quads per thread per k-tile, k-contiguous operand
+  static constexpr int CBN = TN * 4 / NT;       // NN operand: quads per thread per 16-k half
+  static constexpr int CB = NN ? 2 * CBN : TN * 8 / NT;
+  static_assert(MI >= 2 && MI % 2 == 0 && NI >= 2, "wave tile: at least 32 x 32");
+  using Smem = H32Smem<TM, TN>;
+  f32x4 acc[MI][NI];
+
+  __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb, unsigned bytesB,
+                                      int ldb, int row0, int col0, int kbeg, int kend, Pro& pro, int a_rshift = 31,
+                                      unsigned a_blk = 0) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave / WCOLS, wc = wave % WCOLS, r16 = lane & 15, g = lane >> 4;
+    f32x4 loc[MI][NI];   // (unused and optimised away without FOLD)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging map of a k-contiguous operand: eight consecutive lanes cover the 128 bytes (one cache line) of a row's
+    // k-tile, a wave-load is eight whole lines; thread t stages quad kq = t & 7 of rows (t >> 3) + RPK i
+    const int kq = t & 7, srow = t >> 3;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Ab), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bb), 0, (int)bytesB, 0x00020000);
+    const unsigned sA0 = ((ASLICED ? 0u : (unsigned)row0 * lda) + kbeg) * 4u;
+    const unsigned sB0 = (NN ? ((unsigned)kbeg * ldb + col0) : ((unsigned)col0 * ldb + kbeg)) * 4u;
+    // (a k-contiguous operand's passes are RPK rows apart: one VGPR offset, the pass in the scalar offset - except for a
+    // sliced A, whose rows are not equidistant)
+    unsigned aoff[ASLICED ? CA : 1], bgoff[NN ? CBN : 1];
+    if constexpr (ASLICED) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const unsigned r = (unsigned)(row0 + srow + RPK * i);
+        aoff[i] = ((r >> a_rshift) * a_blk + (r & ((1u << a_rshift) - 1u)) * lda + 4 * kq) * 4u;
+      }
+    } else {
+      aoff[0] = ((unsigned)srow * lda + 4 * kq) * 4u;
+    }
+    if constexpr (NN) {
+#pragma unroll
+      for (int i = 0; i < CBN; ++i) bgoff[i] = ((unsigned)(8 * (t / TN) + 4 * i) * ldb + (t % TN)) * 4u;
+    } else {
+      bgoff[0] = ((unsigned)srow * ldb + 4 * kq) * 4u;
+    }
+    const unsigned stepA = (unsigned)RPK * lda * 4u, stepB = (unsigned)RPK * ldb * 4u;
+    const int ntiles = (kend - kbeg) / kH32BK;
+    if (ntiles <= 0) return;
+    auto& smb = *[&]() {
+      if constexpr (SAMEAB) return &sm.a;
+      else return &sm.b;
+    }();
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    f32x4 ra[CA], rb[CB];   // one k-tile (an NN operand: half H in rb[H * CBN ...])
+    // quad i of tile kt (B: index into rb)
+    auto gload_a = [&](int i, int kt) __attribute__((always_inline)) {
+      const unsigned so = sA0 + (unsigned)(kt * kH32BK) * 4u;
+      ra[i] = __builtin_bit_cast(f32x4, ASLICED ? __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[ASLICED ? i : 0], (int)so, 0)
+                                                : __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[0], (int)(so + i * stepA), 0));
+    };
+    auto gload_b = [&](int i, int kt) __attribute__((always_inline)) {
+      if (SAMEAB) return;
+      if constexpr (NN) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int so = (int)(sB0 + (unsigned)(kt * kH32BK + 16 * (i / CBN) + c) * ldb * 4u);
+          rb[i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)bgoff[i % CBN], so, 0));
+        }
+      } else {
+        const int so = (int)(sB0 + (unsigned)(kt * kH32BK) * 4u);
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so + (int)(i * stepB), 0));
+      }
+    };
+    auto gload_all = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) gload_a(i, kt);
+#pragma unroll
+      for (int i = 0; i < CB; ++i) gload_b(i, kt);
+    };
+    auto kpos = [&](int kt) __attribute__((always_inline)) { return kbeg + kt * kH32BK + 4 * kq; };
+    // fp16 offsets of this thread's quads in a plane
+    const int soff = srow * 32 + (((kq >> 1) ^ ((srow >> 2) & 3)) * 8) + (kq & 1) * 4;       // + RPK * 32 per quad
+    const int bcol = t % TN;
+    const int boffn = bcol * 32 + ((((t / TN)) ^ ((bcol >> 2) & 3)) * 8);   // NN, half 0 (half 1: chunk ^ 2 = offset ^ 16)
+    auto a_off = [&](int i) __attribute__((always_inline)) { return soff + RPK * 32 * i; };
+    auto b_off = [&](int i) __attribute__((always_inline)) {      // i: index into rb
+      return NN ? (boffn ^ (16 * (i / CBN))) + 4 * (i % CBN) : soff + RPK * 32 * i;
+    };
+    auto stage_all = [&](auto SET, int st) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        u32x2 p[2];
+        pro.stageA(SET, ra[i], i);
+        split2h(ra[i], 0, p[0], p[1], 0);
+        split2h(ra[i], 2, p[0], p[1], 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x2*>(&sm.a[st][q][a_off(i)]) = p[q];
+      }
+      if (SAMEAB) return;
+#pragma unroll
+      for (int i = 0; i < CB; ++i) {
+        u32x2 p[2];
+        pro.stageB(SET, rb[i], NN ? i % CBN : i);
+        split2h(rb[i], 0, p[0], p[1], 0);
+        split2h(rb[i], 2, p[0], p[1], 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x2*>(&sm.b[st][q][b_off(i)]) = p[q];
+      }
+    };
+
+    if constexpr ((HECKA_ABL & 2) != 0) {   // (stage 1 is never written in the loop: give it finite data)
+      pro.prefetch(S0{}, kpos(0));
+      gload_all(0);
+      stage_all(S0{}, 1);
+    }
+    pro.prefetch(S0{}, kpos(0));
+    gload_all(0);
+    stage_all(S0{}, 0);
+    if (ntiles > 1) {
+      pro.prefetch(S1{}, kpos(1));
+      gload_all(1);
+    }
+    __syncthreads();
+
+    // fragment registers: A in two buffers of (h, l), B as NI x (two slots): B.h of tile kt in slot kt & 1, B.l in the other
+    f16x8 afr[2][2], bfr[NI][2];
+    const int fa = (wr * WM + r16) * 32 + ((g ^ ((r16 >> 2) & 3)) * 8);
+    const int fb = (wc * WN + r16) * 32 + ((g ^ ((r16 >> 2) & 3)) * 8);
+    auto rd_a = [&](int st, int blk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) afr[buf][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][fa + blk * 512]);
+    };
+    auto rd_b = [&](int st, int plane, int slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j][slot] = *reinterpret_cast<const f16x8*>(&smb[st][plane][fb + j * 512]);
+    };
+    rd_b(0, 0, 0);
+    rd_a(0, 0, 0);
+    if constexpr ((HECKA_ABL & 8) != 0) { rd_b(0, 1, 1); rd_a(0, 1, 1); }
+
+    constexpr int NB = 3 * NI, NM = MI * NB;
+    // staging items of a k-tile, two per quad (A quads, then B quads): [prologue transform + split of tile kt + 1's quad,
+    // then the load of tile kt + 2's into the registers just freed - a load has a whole k-tile to arrive] [LDS write]
+    constexpr int NITEMS = 2 * (CA + CB);
+    constexpr int BARG = (MI - 1) * NB + NI - 1;                 // the gap that holds the barrier
+    constexpr int STRIDE = (BARG - 1) / (NITEMS - 1) > 0 ? (BARG - 1) / (NITEMS - 1) : 1;
+    static_assert((NITEMS - 1) * STRIDE < BARG && BARG + 2 < NM, "the staging writes must be issued before the barrier");
+    // (Tried for the eight-wave workgroup, whose waves w and w + 4 share a SIMD and run in lockstep behind the barrier: the
+    // second four waves staging in the second half of the gaps.  dX 1.54 -> 2.35 ms: their stalls then sit right in
+    // front of the barrier, where every wave pays for them.)
+    auto iter = [&](auto PAR, auto FIRST, auto GUARD, int kt) __attribute__((always_inline)) {
+      constexpr int BH = decltype(PAR)::value, BL = 1 - BH;
+      constexpr bool G = decltype(GUARD)::value;
+      using SNEXT = std::integral_constant<int, BL>;   // the prologue's register set of tile kt + 1 (tile kt + 2: PAR)
+      const int st = kt & 1;
+      const bool more = !G || kt + 1 < ntiles;
+      const bool load = (HECKA_ABL & 1) ? false : (!G || kt + 2 < ntiles);
+      const bool more_s = (HECKA_ABL & 2) ? false : more;
+      u32x2 qv[2];
+      auto item = [&](auto R) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        constexpr bool isA = r < 2 * CA;
+        constexpr int quad = (isA ? r : r - 2 * CA) >> 1, step = r & 1;
+        if constexpr (isA || !SAMEAB) {
+          if constexpr (step == 0) {
+            if (more_s) {
+              if constexpr (isA) {
+                pro.stageA(SNEXT{}, ra[quad], quad);
+                split2h(ra[quad], 0, qv[0], qv[1], 0);
+                split2h(ra[quad], 2, qv[0], qv[1], 1);
+              } else {
+                pro.stageB(SNEXT{}, rb[quad], NN ? quad % CBN : quad);
+                split2h(rb[quad], 0, qv[0], qv[1], 0);
+                split2h(rb[quad], 2, qv[0], qv[1], 1);
+              }
+            }
+            if (load) {
+              if constexpr (isA) gload_a(quad, kt + 2);
+              else gload_b(quad, kt + 2);
+            }
+          } else if (more_s) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              if constexpr (isA) *reinterpret_cast<u32x2*>(&sm.a[st ^ 1][q][a_off(quad)]) = qv[q];
+              else *reinterpret_cast<u32x2*>(&sm.b[st ^ 1][q][b_off(quad)]) = qv[q];
+            }
+          }
+        }
+      };
+      static_for<NM>([&](auto N) __attribute__((always_inline)) {
+        constexpr int n = decltype(N)::value;
+        constexpr int i = n / NB, e = (n % NB) / NI, j = n % NI;
+        // product order per row block - first block: hh lh hl (B.l, read at the top of the tile, is used last);
+        // last block: hl hh lh (B.l is dead at the barrier); between: hh hl lh
+        constexpr int prod = i == 0 ? (e == 0 ? 0 : e == 1 ? 2 : 1) : i == MI - 1 ? (e == 0 ? 1 : e == 1 ? 0 : 2) : e;
+        const f16x8 av = afr[i & 1][prod == 2 ? 1 : 0], bv = bfr[j][prod == 1 ? BL : BH];
+        if constexpr ((HECKA_ABL & 16) != 0) {
+        } else if constexpr (FOLD) {
+          f32x4 c = loc[i][j];
+          if constexpr (decltype(FIRST)::value && e == 0) c = f32x4{0.f, 0.f, 0.f, 0.f};
+          loc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr bool RD = (HECKA_ABL & 8) == 0;
+        if constexpr (n == 0) { if (load) pro.prefetch(PAR, kpos(kt + 2)); }
+        if constexpr (RD && n == 0) rd_b(st, 1, BL);
+        if constexpr (RD && n % NB == 1 && i + 1 < MI) rd_a(st, i + 1, (i + 1) & 1);
+        if constexpr (n % STRIDE == 0 && n / STRIDE < NITEMS) item(std::integral_constant<int, n / STRIDE>{});
+        if constexpr (n == BARG && (HECKA_ABL & 4) == 0) __syncthreads();     // tile kt + 1 is complete in stage st ^ 1
+        if constexpr (RD && n == BARG + 1) { if (more) rd_b(st ^ 1, 0, BL); }
+        if constexpr (RD && n == BARG + 2) { if (more) rd_a(st ^ 1, 0, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    auto fold = [&]() __attribute__((always_inline)) {
+      if (!FOLD) return;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i][j][q] += loc[i][j][q];   // v_add_f32, round to nearest
+    };
+    std::true_type T;
+    std::false_type F;
+    int kt = 0;
+    for (; kt + 4 <= ntiles; kt += 2) {   // steady state: both tiles have two tiles behind them
+      iter(S0{}, T, F, kt);
+      iter(S1{}, F, F, kt + 1);
+      fold();
+    }
+    while (kt < ntiles) {
+      iter(S0{}, T, T, kt++);
+      if (kt < ntiles) iter(S1{}, F, T, kt++);
+      fold();
+    }
+  }
+
+  template <class Fn>
+  __device__ __forceinline__ void for_each(Fn&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WCOLS, wc = wave % WCOLS, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f(wr * WM + i * 16 + 4 * g + q, wc * WN + j * 16 + r16, acc[i][j][q]);
+  }
+};
+
+}  // namespace hecka

@@ -10,6 +10,7 @@
 #include "../../include/hecka.h"
 #include "gemm_mfma.hpp"
 #include "gemm_bf16x6.hpp"
+#include "gemm_f16x3_k32.hpp"
 
 namespace hecka {
 
@@ -335,6 +336,28 @@ struct CenterProX6 {
   template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
 
+// The same for the 32-deep tile (gemm_f16x3_k32.hpp): one quad of means per k-tile, four staged rows per thread
+struct CenterProK32 {
+  const float* sbar;
+  float s;
+  f32x4 s4[2];            // means of this thread's k-quad, per tile parity (fetched a whole k-tile ahead)
+  float cav[4], cbv[4];   // per-lane partial dots sbar . (x - sbar), one per staged row (registers are short here)
+  template <class S> __device__ __forceinline__ void prefetch(S, int k) {
+    s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
+  }
+  template <class S> __device__ __forceinline__ void stage(S, f32x4& v, float& acc) {
+    const f32x4 m4 = s4[S::value];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float c = v[e] - m4[e];
+      acc = fmaf(c, m4[e], acc);
+      v[e] = c * s;
+    }
+  }
+  template <class S> __device__ __forceinline__ void stageA(S t, f32x4& v, int i) { stage(t, v, cav[i]); }
+  template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
+};
+
 // RAW (16-bit features only): the MFMA operand is the feature itself - exact in one fp16 term, ONE product per multiply,
 // products exact - and the centring moves to the epilogue: C[a,b] = K[a,b] - u_a with u_a = x_a . sbar = c_a + |sbar|^2
 // (c_a is still accumulated from the centred values in fp32).  K - u cancels where the centred product does not, by the
@@ -429,14 +452,18 @@ __device__ __forceinline__ void gram_raw_x6_body(const void* __restrict__ X, con
   });
 }
 
-template <int SCHEME, int EX = kElemF32, bool RAGGED = false>
+// K32: the 16x16x32 tile of gemm_f16x3_k32.hpp (f16x3, fp32 features, interior shapes, k ranges in multiples of 32)
+template <int SCHEME, int EX = kElemF32, bool RAGGED = false, bool K32 = false>
 __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                     const float* __restrict__ xmax, float* __restrict__ C,
                                                     float* __restrict__ cvec, int B, int P, int ntile, int xcd_map,
                                                     int w, int kbeg, int kend, int slice_rshift = 31, int Mlay = 0) {
-  using Pro = CenterProX6<SCHEME, RAGGED>;
-  using Tile = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, false, RAGGED>;
-  using TileD = GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, true, RAGGED>;   // diagonal tiles
+  static_assert(!K32 || (SCHEME == 1 && EX == kElemF32 && !RAGGED), "the k-32 tile: f16x3 on fp32 features, interior shapes");
+  using Pro = std::conditional_t<K32, CenterProK32, CenterProX6<SCHEME, RAGGED>>;
+  using Tile = std::conditional_t<K32, GemmTileH32<128, 128, false, Pro, true, false>,
+                                  GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, false, RAGGED>>;
+  using TileD = std::conditional_t<K32, GemmTileH32<128, 128, false, Pro, true, true>,     // diagonal tiles
+                                   GemmTileX6<128, 128, false, Pro, SCHEME, true, EX, EX, true, true, true, RAGGED>>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   __shared__ float cA[128], cB[128];
@@ -449,35 +476,47 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
 #else
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * ES;
 #endif
+  // staged rows per thread, lanes that share a staged row, rows per staging pass (GemmTileX6 / GemmTileH32 thread maps)
+  constexpr int NQ = K32 ? 4 : 2, LR = K32 ? 8 : 4, RP = 256 / LR;
   Pro pro;
-  pro.klim = P;
+  if constexpr (!K32) pro.klim = P;
   pro.sbar = sbar + (size_t)m * P;
   pro.s = SCHEME == 1 ? pow2_scale(xmax[m], 13) : 1.0f;
-  pro.cav[0] = pro.cav[1] = pro.cbv[0] = pro.cbv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    if constexpr (K32) pro.cav[i] = pro.cbv[i] = 0.f;
+    else pro.cav[i] = pro.cbv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const float unscale = SCHEME == 1 ? 1.0f / (pro.s * pro.s) : 1.0f;
   Tile tile;
   if (HECKA_DIAG_TILES && I == J) {
     TileD td;
     td.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, kbeg, kend, pro);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < Tile::MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tile.acc[i][j] = td.acc[i][j];
-    pro.cbv[0] = pro.cav[0];
-    pro.cbv[1] = pro.cav[1];
+      for (int j = 0; j < Tile::NI; ++j) tile.acc[i][j] = td.acc[i][j];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) pro.cbv[i] = pro.cav[i];
   } else {
     tile.run(sm, Xm, (unsigned)B * P * ES, P, Xm, (unsigned)B * P * ES, P, I * 128, J * 128, kbeg, kend, pro);
   }
-  // c_b = sbar . (x_b - sbar): four consecutive lanes share a staged row
+  // c_b = sbar . (x_b - sbar): LR consecutive lanes share a staged row
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    float a = pro.cav[i][0] + pro.cav[i][1] + pro.cav[i][2] + pro.cav[i][3];
-    float b = pro.cbv[i][0] + pro.cbv[i][1] + pro.cbv[i][2] + pro.cbv[i][3];
-    a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
-    a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
-    if ((threadIdx.x & 3) == 0) {
-      cA[(threadIdx.x >> 2) + 64 * i] = a;
-      cB[(threadIdx.x >> 2) + 64 * i] = b;
+  for (int i = 0; i < NQ; ++i) {
+    float a, b;
+    if constexpr (K32) {
+      a = pro.cav[i];
+      b = pro.cbv[i];
+    } else {
+      a = pro.cav[i][0] + pro.cav[i][1] + pro.cav[i][2] + pro.cav[i][3];
+      b = pro.cbv[i][0] + pro.cbv[i][1] + pro.cbv[i][2] + pro.cbv[i][3];
+    }
+#pragma unroll
+    for (int d = 1; d < LR; d *= 2) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if ((threadIdx.x & (LR - 1)) == 0) {
+      cA[threadIdx.x / LR + RP * i] = a;
+      cB[threadIdx.x / LR + RP * i] = b;
     }
   }
   __syncthreads();
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(256) void gram_split_reduce_kernel(GramMultiArgs a,
   }
 }
 
-template <int SCHEME, int EX = kElemF32, bool RAW = false, bool RAGGED = false>
+template <int SCHEME, int EX = kElemF32, bool RAW = false, bool RAGGED = false, bool K32 = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramMultiArgs a, int B, int ntile, int xcd_map,
                                                                            int slice_rshift) {
   static_assert(!(RAW && RAGGED), "the raw 16-bit Gram is written for interior shapes");
@@ -587,7 +626,7 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
     cvec = cws + (size_t)z * a.M * B;
   }
   if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
-  else gram_center_x6_body<SCHEME, EX, RAGGED>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend, slice_rshift, a.M);
+  else gram_center_x6_body<SCHEME, EX, RAGGED, K32>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend, slice_rshift, a.M);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1052,13 +1091,15 @@ struct ScaleProX6 {
 // TM = 256 (no local chains only): each wave owns 128 x 64 of a 256 x 128 tile - a staged X tile feeds twice the MFMAs
 // (24 per k-tile per wave behind one barrier), fragment reads and staging work per MFMA fall by a quarter; two
 // workgroups per CU (128 accumulator registers per lane).
-template <int SCHEME, bool FOLD, int EX, int TM, bool RAGGED, bool SLICED, int TN = 128>
+template <int SCHEME, bool FOLD, int EX, int TM, bool RAGGED, bool SLICED, int TN = 128, bool K32 = false>
 __device__ __forceinline__ void gram_bwd_x6_body(const float* __restrict__ W, const void* __restrict__ X,
                                                  const unsigned* __restrict__ wmax, const float* __restrict__ xmax,
                                                  void* __restrict__ dX, int B, int P, int tilesM, int tilesN, int xcd_map,
                                                  const float* __restrict__ gate, int w, int M, int slice_rshift) {
   static_assert(TM == 128 || !FOLD, "the 256-row tile has no registers for local chains");
-  using Tile = GemmTileX6<TM, TN, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED, SLICED, 2 * TN>;
+  static_assert(!K32 || (SCHEME == 1 && EX == kElemF32 && !RAGGED), "the k-32 tile: f16x3 on fp32 features, interior shapes");
+  using Tile = std::conditional_t<K32, GemmTileH32<TM, TN, true, ScaleProX6<SCHEME>, FOLD, false, SLICED, 2 * TN>,
+                                  GemmTileX6<TM, TN, true, ScaleProX6<SCHEME>, SCHEME, FOLD, kElemF32, EX, EX == kElemF32, true, false, RAGGED, SLICED, 2 * TN>>;
   constexpr unsigned ES = elem_bytes<EX>();
   __shared__ typename Tile::Smem sm;
   int m, tl;
@@ -1121,7 +1162,7 @@ struct BwdMultiArgs {
   int L, M;
 };
 
-template <int TM, bool RAGGED, bool SLICED, int TN = 128>
+template <int TM, bool RAGGED, bool SLICED, int TN = 128, bool K32 = false>
 __global__ __launch_bounds__(2 * TN, TN == 256 ? 1 : (TM == 256 ? 2 : 3)) void gram_bwd_x6_multi_kernel(BwdMultiArgs a, int B, int tilesM, int xcd_map,
                                                                                        const float* __restrict__ gate,
                                                                                        int slice_rshift) {
@@ -1136,7 +1177,7 @@ __global__ __launch_bounds__(2 * TN, TN == 256 ? 1 : (TM == 256 ? 2 : 3)) void g
 #pragma unroll
   for (int i = 1; i < kMaxGramLayers; ++i)
     if (i == li) { W = a.l[i].W; X = a.l[i].X; wmax = a.l[i].wmax; xmax = a.l[i].xmax; dX = a.l[i].dX; P = a.l[i].P; }
-  gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED, TN>(W, X, wmax, xmax, dX, B, P, tilesM, (P + TN - 1) / TN, xcd_map, gate,
+  gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED, TN, K32>(W, X, wmax, xmax, dX, B, P, tilesM, (P + TN - 1) / TN, xcd_map, gate,
                                                               w - w0, a.M, slice_rshift);
 }
 
@@ -2513,6 +2554,12 @@ static inline bool ragged_x3_wanted(long long nwg) {
   return e ? atoi(e) != 0 : nwg >= small_grid();
 }
 
+// HECKA_K32=0: keep the f16x3 Gram / wide dX on the 32x32x16 tile (GemmTileX6) instead of the 16x16x32 one (GemmTileH32)
+static inline bool k32_wanted() {
+  const char* e = getenv("HECKA_K32");
+  return !e || atoi(e) != 0;
+}
+
 static int slice_shift(int B, int slice_rows) {      // log2(slice_rows) for a power of two that divides B, else -1
   if (slice_rows <= 0 || (slice_rows & (slice_rows - 1)) || B % slice_rows) return -1;
   int s = 0;
@@ -2679,8 +2726,9 @@ static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, in
   size_t bytes = 0;
   for (int i = 0; i < L; ++i) {
     long long ns = std::min<long long>(8, std::max<long long>(1, (P[i] + dstar / 2) / dstar));
-    const long long tiles16 = (P[i] + 15) / 16;
-    long long kc = ((tiles16 + ns - 1) / ns) * 16;
+    const long long unit = P[i] % 32 == 0 ? 32 : 16;     // (whole k-tiles of the 16x16x32 tile where the layer allows it)
+    const long long tiles16 = (P[i] + unit - 1) / unit;
+    long long kc = ((tiles16 + ns - 1) / ns) * unit;
     ns = (P[i] + kc - 1) / kc;
     nsplit[i] = (int)ns;
     kchunk[i] = (int)kc;
@@ -2784,9 +2832,15 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
     if (!have_max) return fail(HECKA_EINVAL, "gram_center_multi: ragged shapes need xmax%s");
     hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, true>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B,
                        ntile, xcd, rs);
-  } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO)
-    hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs);
-  else
+  } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO) {
+    bool k32 = k32_wanted();
+    for (int i = 0; i < L; ++i) k32 = k32 && P[i] % 32 == 0 && kch[i] % 32 == 0;
+    if (k32)
+      hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, false, true>), dim3((unsigned)wg), dim3(kThreads), 0,
+                         st, a, B, ntile, xcd, rs);
+    else
+      hipLaunchKernelGGL(gram_center_x6_multi_kernel<1>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs);
+  } else
     hipLaunchKernelGGL(gram_center_x6_multi_kernel<0>, dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, ntile, xcd, rs);
   if (int rc = check_launch("gram_center_multi")) return rc;
   if (any_split) {
@@ -3832,7 +3886,12 @@ int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X
   const int xcd = (int)(M % 8 == 0), rs = slice_rows ? slice_shift(B, slice_rows) : 31;
 #define HECKA_BWDM(TMV, RAG, SL) \
   hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<TMV, RAG, SL>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B, tilesM, xcd, gate, rs)
-  if (wide) {
+  if (wide && k32_wanted()) {
+    if (slice_rows)
+      hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, true, 256, true>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
+    else
+      hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, false, 256, true>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
+  } else if (wide) {
     if (slice_rows)
       hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, true, 256>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
     else

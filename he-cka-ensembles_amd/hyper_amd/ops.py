@@ -416,8 +416,10 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
         interior = B % 128 == 0 and all(X.shape[2] % 128 == 0 for X in Xs)
         tm = 256 if interior and B % 256 == 0 else 128
         wide = tm == 256 and all(X.shape[2] % 256 == 0 for X in Xs) and os.environ.get('HECKA_BWD_TN', '256') == '256'
-        LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s, %d>' % (tm, 'false' if interior else 'true',
-                                                                         'true' if slice_rows else 'false', 256 if wide else 128)
+        k32 = wide and os.environ.get('HECKA_K32', '1') != '0'      # the 16x16x32 tile (gemm_f16x3_k32.hpp)
+        LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s, %d, %s>' % (
+            tm, 'false' if interior else 'true', 'true' if slice_rows else 'false', 256 if wide else 128,
+            'true' if k32 else 'false')
     _GemmChain.leave(Xs[0].device, chain)
     return dXs
 

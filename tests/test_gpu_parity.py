@@ -390,7 +390,7 @@ def test_16bit_features_match_oracle_on_rounded_values(dtype, native, dims, monk
 def test_native_16bit_equals_upcast_path(exact, monkeypatch):
     """The x16 kernels against the fp32 kernels on the up-cast copy of the same bf16 features, bench member/sample
     counts.  exact (HECKA_X16_EXACT=1): same loss to 1e-6 and gradients that differ by at most one bf16 ulp (both round
-    an fp32-accurate value once).  Default (raw one-product Gram): loss to 1e-4, gradients to one ulp + 1e-4 of the
+    an fp32-accurate value once) plus 2e-6 of the largest.  Default (raw one-product Gram): loss to 1e-4, gradients to one ulp + 1e-4 of the
     largest."""
     from hyper_amd.diversity.model_kernels import build_model_kernel
     from collections import OrderedDict
@@ -414,7 +414,10 @@ def test_native_16bit_equals_upcast_path(exact, monkeypatch):
     assert abs(res['1'][0] - res['0'][0]) <= (1e-6 if exact else 1e-4) * abs(res['0'][0])
     for g1, g0 in zip(res['1'][1], res['0'][1]):
         d = (g1.float() - g0.float()).abs()
-        ulp = g0.float().abs() * 2.0 ** -7 + (1e-30 if exact else 1e-4 * float(g0.float().abs().max()))
+        # (exact: the fp32 path runs its Gram / dX on the 16x16x32 tile, the 16-bit path on the 32x32x16 one - two fp32
+        # summation orders, so elements that cancel to near zero differ by fp32 rounding of the LARGEST terms, not by a
+        # relative ulp of their own value)
+        ulp = g0.float().abs() * 2.0 ** -7 + (2e-6 if exact else 1e-4) * float(g0.float().abs().max())
         assert bool((d <= ulp).all())
         if exact:
             assert float((d > 0).float().mean()) < 0.02      # the two roundings disagree only near a rounding boundary

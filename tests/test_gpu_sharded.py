@@ -55,7 +55,7 @@ def test_combine_slice_equals_full_combine(M, B):
                                           (8, 256, (384, 128), 128), (128, 400, (256, 864), 0), (8, 384, (256, 128), 0)])
 def test_multi_layer_dx_and_slice_major_layouts_are_bit_equal(M, B, Ps, rows, monkeypatch):
     """ONE dX launch for all layers (hecka_gram_bwd_multi_f32) == the per-layer launches, bit for bit (same tile code,
-    same accumulation order) - interior and ragged shapes; and with `rows` > 0 the slice-major layouts of the member-
+    same accumulation order; see `wide` below for the eight-wave tile) - interior and ragged shapes; and with `rows` > 0 the slice-major layouts of the member-
     sharded path: the Gram written as [B/rows, M, rows, B] is the standard Gram permuted, and dX from a W in that order
     equals dX from the standard W."""
     from hyper_amd import ops
@@ -72,6 +72,18 @@ def test_multi_layer_dx_and_slice_major_layouts_are_bit_equal(M, B, Ps, rows, mo
     one = [ops.gram_bwd_w(W, X, wm, xm) for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)]
     monkeypatch.delenv('HECKA_BWD_MULTI')            # ... against one launch (256 x 256 eight-wave tiles where every P % 256 == 0)
     many = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)
+    wide = B % 256 == 0 and all(p % 256 == 0 for p in Ps)
+    if wide:
+        # the eight-wave launch runs the 16x16x32 tile (gemm_f16x3_k32.hpp): another fp32 summation order than the four-wave
+        # 32x32x16 tiles - equal to rounding, and bit-equal to the same tile launched layer by layer ...
+        for a, b in zip(one, many):
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+        one = [ops.gram_bwd_multi([W], [X], [wm], [xm])[0] for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)]
+        monkeypatch.setenv('HECKA_K32', '0')         # ... and with that tile switched off, to the four-wave launches
+        for a, b in zip([ops.gram_bwd_w(W, X, wm, xm) for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)],
+                        ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)):
+            assert torch.equal(a, b)
+        monkeypatch.delenv('HECKA_K32')
     for a, b in zip(one, many):
         assert torch.equal(a, b)
     ref = Ws[0].double() @ Xs[0].double()
