@@ -12,7 +12,8 @@
 // Staging: eight lanes load the 128 bytes of one row's k-tile - whole cache lines (GemmTileX6's 16-deep tiles take a line in
 // two halves, a k-tile apart: with the lines of 2 x 256 rows in flight per CU the second half rarely still sits in the
 // L1, and the ablation builds (HECKA_ABL) showed the Gram kernel bound by its load path, not by the MFMAs).  An NN operand
-// is gathered column-wise, 16 k (one half of the tile) at a time.
+// is loaded as it lies (a wave-load = 1 KiB of one k-row), stored untransposed and read with the transposing
+// ds_read_b64_tr_b16 (a quarter of the load instructions of a column-wise dword gather).
 //
 // Schedule of one k-tile (per wave: MI row blocks x NI column blocks of 16 x 16, 3 MI NI MFMAs of 16 cycles):
 //   * all B fragments stay in registers for the tile, A fragments are streamed one row block ahead (two buffers);
@@ -29,7 +30,8 @@ namespace hecka {
 
 constexpr int kH32BK = 32;
 // Diagnostic builds only (csrc/lab, wrong results on purpose): HECKA_ABL removes one part of the k-tile loop to see what it
-// costs - 1: the global loads, 2: split + LDS writes, 4: the barrier, 8: the fragment reads, 16: the MFMAs.
+// costs - 1: the global loads (32: A's only, 64: B's only), 2: split + LDS writes, 4: the barrier, 8: the fragment
+// reads, 16: the MFMAs.
 #ifndef HECKA_ABL
 #define HECKA_ABL 0
 #endif
@@ -44,10 +46,17 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int TM, int TN>
+// An NN operand keeps the orientation it has in memory: panels of 16 columns, each [32 k-rows][16 columns] (32-byte rows,
+// in the order kH32RowPos - the 8 rows that the two 16-lane groups of a half-wave read together lie in 256 contiguous
+// bytes), panels 1056 bytes apart (so that a wave's stores of one k-row spread over the banks).
+constexpr int kH32Panel = 528;   // fp16 per panel: 32 rows x 16 columns + 16 pad
+__device__ __forceinline__ constexpr int h32_row_pos(int r) {   // position of k-row r inside a panel
+  return (r & 3) + 4 * ((r >> 3) & 1) + 8 * ((r >> 2) & 1) + 16 * (r >> 4);
+}
+template <int TM, int TN, bool NN>
 struct H32Smem {
   alignas(16) unsigned short a[2][2][TM * 32];   // [stage][plane h / l][row * 32 + swizzled k]
-  alignas(16) unsigned short b[2][2][TN * 32];
+  alignas(16) unsigned short b[2][2][NN ? (TN / 16) * kH32Panel : TN * 32];
 };
 
 // A [rows, K] (k contiguous); NN = false: B [cols, K]; NN = true: B [K, cols].  rows / cols multiples of the tile,
@@ -63,10 +72,11 @@ struct GemmTileH32 {
   static constexpr int WCOLS = NT / 128;
   static constexpr int WM = TM / 2, WN = TN / WCOLS, MI = WM / 16, NI = WN / 16;
   static constexpr int CA = TM * 8 / NT;        // quads per thread per k-tile, k-contiguous operand
-  static constexpr int CBN = TN * 4 / NT;       // NN operand: quads per thread per 16-k half
-  static constexpr int CB = NN ? 2 * CBN : TN * 8 / NT;
+  static constexpr int CB = TN * 8 / NT;        // ... of B: k-contiguous as A; NN: TN / 4 lanes load one k-row (four
+                                                // consecutive columns each), NT / (TN / 4) = 8 k-rows per pass
+  static constexpr int LPR = TN / 4;            // NN: lanes per k-row
   static_assert(MI >= 2 && MI % 2 == 0 && NI >= 2, "wave tile: at least 32 x 32");
-  using Smem = H32Smem<TM, TN>;
+  using Smem = H32Smem<TM, TN, NN>;
   f32x4 acc[MI][NI];
 
   __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb, unsigned bytesB,
@@ -89,7 +99,7 @@ struct GemmTileH32 {
     const unsigned sB0 = (NN ? ((unsigned)kbeg * ldb + col0) : ((unsigned)col0 * ldb + kbeg)) * 4u;
     // (a k-contiguous operand's passes are RPK rows apart: one VGPR offset, the pass in the scalar offset - except for a
     // sliced A, whose rows are not equidistant)
-    unsigned aoff[ASLICED ? CA : 1], bgoff[NN ? CBN : 1];
+    unsigned aoff[ASLICED ? CA : 1], bgoff[1];
     if constexpr (ASLICED) {
 #pragma unroll
       for (int i = 0; i < CA; ++i) {
@@ -99,12 +109,10 @@ struct GemmTileH32 {
     } else {
       aoff[0] = ((unsigned)srow * lda + 4 * kq) * 4u;
     }
-    if constexpr (NN) {
-#pragma unroll
-      for (int i = 0; i < CBN; ++i) bgoff[i] = ((unsigned)(8 * (t / TN) + 4 * i) * ldb + (t % TN)) * 4u;
-    } else {
-      bgoff[0] = ((unsigned)srow * ldb + 4 * kq) * 4u;
-    }
+    const int krow = __builtin_amdgcn_readfirstlane(t / LPR);   // NN: this wave's k-row of a pass (LPR is a multiple of 64)
+    static_assert(!NN || LPR % 64 == 0, "NN operand: whole waves per k-row");
+    if constexpr (NN) bgoff[0] = (unsigned)(t % LPR) * 16u;
+    else bgoff[0] = ((unsigned)srow * ldb + 4 * kq) * 4u;
     const unsigned stepA = (unsigned)RPK * lda * 4u, stepB = (unsigned)RPK * ldb * 4u;
     const int ntiles = (kend - kbeg) / kH32BK;
     if (ntiles <= 0) return;
@@ -115,7 +123,7 @@ struct GemmTileH32 {
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    f32x4 ra[CA], rb[CB];   // one k-tile (an NN operand: half H in rb[H * CBN ...])
+    f32x4 ra[CA], rb[CB];   // one k-tile (NN: quad i = k-row krow + 8 i)
     // quad i of tile kt (B: index into rb)
     auto gload_a = [&](int i, int kt) __attribute__((always_inline)) {
       const unsigned so = sA0 + (unsigned)(kt * kH32BK) * 4u;
@@ -124,12 +132,9 @@ struct GemmTileH32 {
     };
     auto gload_b = [&](int i, int kt) __attribute__((always_inline)) {
       if (SAMEAB) return;
-      if constexpr (NN) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int so = (int)(sB0 + (unsigned)(kt * kH32BK + 16 * (i / CBN) + c) * ldb * 4u);
-          rb[i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)bgoff[i % CBN], so, 0));
-        }
+      if constexpr (NN) {   // four columns of one k-row: a wave-load is 1 KiB of that row, the row in the scalar offset
+        const int so = (int)(sB0 + (unsigned)(kt * kH32BK + krow + 8 * i) * ldb * 4u);
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so, 0));
       } else {
         const int so = (int)(sB0 + (unsigned)(kt * kH32BK) * 4u);
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so + (int)(i * stepB), 0));
@@ -144,11 +149,11 @@ struct GemmTileH32 {
     auto kpos = [&](int kt) __attribute__((always_inline)) { return kbeg + kt * kH32BK + 4 * kq; };
     // fp16 offsets of this thread's quads in a plane
     const int soff = srow * 32 + (((kq >> 1) ^ ((srow >> 2) & 3)) * 8) + (kq & 1) * 4;       // + RPK * 32 per quad
-    const int bcol = t % TN;
-    const int boffn = bcol * 32 + ((((t / TN)) ^ ((bcol >> 2) & 3)) * 8);   // NN, half 0 (half 1: chunk ^ 2 = offset ^ 16)
+    // NN: panel (t % LPR) / 4, columns 4 (t & 3) ..; quad i is k-row krow + 8 i: position (krow & 3) + 8 (krow >> 2) + 4 (i & 1) + 16 (i >> 1)
+    const int boffn = ((t % LPR) >> 2) * kH32Panel + ((krow & 3) + 8 * (krow >> 2)) * 16 + (t & 3) * 4;
     auto a_off = [&](int i) __attribute__((always_inline)) { return soff + RPK * 32 * i; };
     auto b_off = [&](int i) __attribute__((always_inline)) {      // i: index into rb
-      return NN ? (boffn ^ (16 * (i / CBN))) + 4 * (i % CBN) : soff + RPK * 32 * i;
+      return NN ? boffn + (4 * (i & 1) + 16 * (i >> 1)) * 16 : soff + RPK * 32 * i;
     };
     auto stage_all = [&](auto SET, int st) __attribute__((always_inline)) {
 #pragma unroll
@@ -164,7 +169,7 @@ struct GemmTileH32 {
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         u32x2 p[2];
-        pro.stageB(SET, rb[i], NN ? i % CBN : i);
+        pro.stageB(SET, rb[i], i);
         split2h(rb[i], 0, p[0], p[1], 0);
         split2h(rb[i], 2, p[0], p[1], 1);
 #pragma unroll
@@ -189,14 +194,28 @@ struct GemmTileH32 {
     // fragment registers: A in two buffers of (h, l), B as NI x (two slots): B.h of tile kt in slot kt & 1, B.l in the other
     f16x8 afr[2][2], bfr[NI][2];
     const int fa = (wr * WM + r16) * 32 + ((g ^ ((r16 >> 2) & 3)) * 8);
-    const int fb = (wc * WN + r16) * 32 + ((g ^ ((r16 >> 2) & 3)) * 8);
+    // NN: ds_read_b64_tr_b16 - lane 4 q + p of 16-lane group g addresses k-row 8 g + 4 e + q, columns 4 p .. 4 p + 3 of
+    // the block's panel, and receives its column's four k (e = 0, 1: the two halves of the lane's eight k)
+    const int fb = NN ? ((wc * WN) / 16) * kH32Panel + (((lane >> 2) & 3) + 4 * (g & 1) + 16 * (g >> 1)) * 16 + (lane & 3) * 4
+                      : (wc * WN + r16) * 32 + ((g ^ ((r16 >> 2) & 3)) * 8);
     auto rd_a = [&](int st, int blk, int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int p = 0; p < 2; ++p) afr[buf][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][fa + blk * 512]);
     };
     auto rd_b = [&](int st, int plane, int slot) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j][slot] = *reinterpret_cast<const f16x8*>(&smb[st][plane][fb + j * 512]);
+      for (int j = 0; j < NI; ++j) {
+        if constexpr (NN) {
+          typedef short s16x4_ __attribute__((ext_vector_type(4)));
+          typedef short s16x8_ __attribute__((ext_vector_type(8)));
+          typedef __attribute__((address_space(3))) s16x4_* lds4;
+          const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&smb[st][plane][fb + j * kH32Panel]));
+          const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(&smb[st][plane][fb + j * kH32Panel + 128]));
+          bfr[j][slot] = __builtin_bit_cast(f16x8, s16x8_{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        } else {
+          bfr[j][slot] = *reinterpret_cast<const f16x8*>(&smb[st][plane][fb + j * 512]);
+        }
+      }
     };
     rd_b(0, 0, 0);
     rd_a(0, 0, 0);
@@ -233,14 +252,14 @@ struct GemmTileH32 {
                 split2h(ra[quad], 0, qv[0], qv[1], 0);
                 split2h(ra[quad], 2, qv[0], qv[1], 1);
               } else {
-                pro.stageB(SNEXT{}, rb[quad], NN ? quad % CBN : quad);
+                pro.stageB(SNEXT{}, rb[quad], quad);
                 split2h(rb[quad], 0, qv[0], qv[1], 0);
                 split2h(rb[quad], 2, qv[0], qv[1], 1);
               }
             }
             if (load) {
-              if constexpr (isA) gload_a(quad, kt + 2);
-              else gload_b(quad, kt + 2);
+              if constexpr (isA) { if constexpr ((HECKA_ABL & 32) == 0) gload_a(quad, kt + 2); }
+              else if constexpr ((HECKA_ABL & 64) == 0) gload_b(quad, kt + 2);
             }
           } else if (more_s) {
 #pragma unroll
