@@ -887,12 +887,17 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {   // 256-thr
 // C[2 ks + h][n0 + 2 j .. + 1]: 256 contiguous bytes per half-wave, no LDS round trip), 32 k-steps x RB x 2
 // v_mfma_f32_32x32x2_f32 per chunk, and the epilogue adds the gamma terms and stores float2.  HBM-bound: reads C once,
 // writes W once.
-template <int RB>
+// FIXG (the chunk range is whole Gram rows and the grid a multiple of the B / 64 column strips): a workgroup keeps ONE
+// column strip - wave w takes Gram rows, not chunks, in turn - so the column terms gamma[:, b] of the epilogue are the same
+// 64 x 64 block for every chunk: loaded into LDS once instead of 32 dependent 8-byte loads per chunk (226 -> 18x us for
+// the bench's five layers).
+template <int RB, bool FIXG = false>
 __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __restrict__ A, const float* __restrict__ C,
                                                                 const float* __restrict__ gamma, int B, int detach_diag,
                                                                 float* __restrict__ W, long long N, long long chunk0) {
   __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]
   __shared__ float sG[4][32 * RB];   // per wave: gamma[:, a] of the chunk's Gram row a
+  __shared__ float sGC[FIXG ? 32 * RB : 1][FIXG ? 64 : 2];   // FIXG: gamma[:, b0 .. b0 + 63] of the workgroup's strip
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, j = lane & 31;
   // blockIdx.y: layer of a batched call (A [L,Ma,64], C [L,64,N], gamma [L,Ma,B], W [L,Ma,N] contiguous)
   A += (size_t)blockIdx.y * (32 * RB * 64);
@@ -903,11 +908,15 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
     const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
     sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
   }
-  __syncthreads();
   // C and W hold N columns per row: the Gram elements [64 chunk0, 64 chunk0 + N) of the B*B (all of them when
   // chunk0 = 0 and N = B*B; a column slice in the member-sharded path)
   const int strips = B / 64;
   const long long nchunks = N / 64;
+  if constexpr (FIXG) {
+    const int b0s = (int)(blockIdx.x % strips) * 64;
+    for (int e = t; e < 32 * RB * 64; e += 256) sGC[e >> 6][e & 63] = gamma[(size_t)(e >> 6) * B + b0s + (e & 63)];
+  }
+  __syncthreads();
   // buffer addressing: one per-lane byte offset per chunk + scalar row offsets (no 64-bit pointers kept per row)
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C), 0, (int)(64 * N * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(W, 0, (int)(32 * RB * N * 4), 0x00020000);
@@ -915,8 +924,9 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   const unsigned rowN = (unsigned)N * 4u;
   // chunk c (global chunk cg = chunk0 + c) -> Gram row a = cg / strips, columns b0 = 64 (cg % strips); the B fragments of the wave's NEXT chunk are
   // loaded while the 128 MFMAs of the current one issue (two register sets)
-  const long long cstep = (long long)gridDim.x * 4;
-  long long c = (long long)blockIdx.x * 4 + wave;
+  // (FIXG: chunk = Gram row * strips + this workgroup's strip, rows dealt to the waves of the workgroups that share it)
+  const long long cstep = FIXG ? (long long)(gridDim.x / strips) * 4 * strips : (long long)gridDim.x * 4;
+  long long c = FIXG ? ((long long)(blockIdx.x / strips) * 4 + wave) * strips + blockIdx.x % strips : (long long)blockIdx.x * 4 + wave;
   f32x2 bf[2][32];
   auto load_b = [&](auto SET, long long cc) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
@@ -958,7 +968,9 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int ib = rb * 32 + (q & 3) + 8 * (q >> 2);   // row i = ib + 4 h
-        const f32x2 gc = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsG, (int)vG, ib * B * 4, 0));
+        f32x2 gc;
+        if constexpr (FIXG) gc = *reinterpret_cast<const f32x2*>(&sGC[ib + 4 * h][2 * j]);
+        else gc = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsG, (int)vG, ib * B * 4, 0));
         const float gr = sG[wave][ib + 4 * h];
         f32x2 w = {2.f * acc[rb][0][q] + gr - gc[0], 2.f * acc[rb][1][q] + gr - gc[1]};
         if (detach_diag) {
@@ -2554,6 +2566,16 @@ static inline bool ragged_x3_wanted(long long nwg) {
   return e ? atoi(e) != 0 : nwg >= small_grid();
 }
 
+// The streaming combine's fixed-strip form (combine_stream_kernel<RB, true>): the chunk range must be whole Gram rows and
+// the grid a multiple of the B / 64 column strips (rounded down here).  HECKA_COMBINE_FIXG=0 switches it off.
+static inline bool combine_fixg(int B, long long N, long long n_start, unsigned& nwg) {
+  const char* e = getenv("HECKA_COMBINE_FIXG");
+  const unsigned strips = (unsigned)(B / 64);
+  if ((e && atoi(e) == 0) || strips == 0 || N % B != 0 || n_start % B != 0 || nwg < strips) return false;
+  nwg -= nwg % strips;
+  return true;
+}
+
 // HECKA_K32=0: keep the f16x3 Gram / wide dX on the 32x32x16 tile (GemmTileX6) instead of the 16x16x32 one (GemmTileH32)
 static inline bool k32_wanted() {
   const char* e = getenv("HECKA_K32");
@@ -3015,9 +3037,16 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
   if (mode == 1 && Mb == 64 && (Ma == 64 || Ma == 32) && B % 64 == 0 && N % 64 == 0 && n_start % 64 == 0 && aligned16(A) &&
       aligned16(C) && aligned16(gamma) && aligned16(W) && 64ll * N * 4 < (1ll << 32) && !getenv("HECKA_COMBINE_TILED")) {
     const char* ge = getenv("HECKA_COMBINE_WGS");
-    const unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, ge ? atoi(ge) : 512));
-    if (Ma == 64)
+    unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, ge ? atoi(ge) : 512));
+    const bool fixg = combine_fixg(B, N, n_start, nwg);
+    if (Ma == 64 && fixg)
+      hipLaunchKernelGGL((combine_stream_kernel<2, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+                         n_start / 64);
+    else if (Ma == 64)
       hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+                         n_start / 64);
+    else if (fixg)
+      hipLaunchKernelGGL((combine_stream_kernel<1, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
                          n_start / 64);
     else
       hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
@@ -3079,10 +3108,17 @@ int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, con
     return HECKA_OK;
   }
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
-  if (Ma == 64)
+  unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
+  const bool fixg = combine_fixg(B, N, n_start, nwg);
+  if (Ma == 64 && fixg)
+    hipLaunchKernelGGL((combine_stream_kernel<2, true>), dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag,
+                       Ws_all, N, n_start / 64);
+  else if (Ma == 64)
     hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
                        N, n_start / 64);
+  else if (fixg)
+    hipLaunchKernelGGL((combine_stream_kernel<1, true>), dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag,
+                       Ws_all, N, n_start / 64);
   else
     hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
                        N, n_start / 64);
