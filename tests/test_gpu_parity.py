@@ -1040,6 +1040,41 @@ def test_multi_gram_split_k_matches_unsplit(dtype, monkeypatch):
         assert _relerr(g.numpy(), o.grad.numpy()) <= tol
 
 
+@pytest.mark.parametrize('M,B,dims,rows', [(64, 512, (1024, 512), 0), (8, 256, (2048, 256), 64), (16, 128, (96, 32), 0)])
+def test_k32_tile_equals_x6_tile_to_rounding(M, B, dims, rows, monkeypatch):
+    """The 32-deep 16x16x32 tile (gemm_f16x3_k32.hpp: all-layers Gram, 256 x 256 dX launch) against the 16-deep 32x32x16 tile
+    it replaces (HECKA_K32=0) on the same operands: the same two-term products in another summation order - C, cvec and
+    dX equal to 2e-6 of their largest element, in the standard and (rows > 0) the slice-major layouts; and both within
+    2e-6 of the fp64 products."""
+    from hyper_amd import ops
+    dev = _dev()
+    torch.manual_seed(B + M)
+    Xs = [(torch.relu(torch.randn(M, B, p, device=dev)) + 0.05 * i) for i, p in enumerate(dims)]
+    Ws = [torch.randn(M, B, B, device=dev) for _ in dims]
+    wmaxs = [W.abs().amax(dim=(1, 2)) for W in Ws]
+    res = {}
+    for k32 in ('1', '0'):
+        monkeypatch.setenv('HECKA_K32', k32)
+        g = ops.centered_gram_multi(Xs, slice_rows=rows)
+        xmaxs = [t[2] for t in g]
+        dx = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs) if ops.gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs) else \
+            [ops.gram_bwd_w(W, X, wm, xm) for W, X, wm, xm in zip(Ws, Xs, wmaxs, xmaxs)]
+        res[k32] = ([t[0].clone() for t in g], [t[1].clone() for t in g], dx)
+    for li in range(len(dims)):
+        for a, b in zip((res['1'][0][li], res['1'][1][li], res['1'][2][li]), (res['0'][0][li], res['0'][1][li], res['0'][2][li])):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+        Xd = Xs[li].double()
+        Xc = Xd - Xd.mean(1, keepdim=True)
+        Cref = Xd @ Xc.transpose(1, 2)      # C[a, b] = x_a . (x_b - mean): the centred Gram plus the 1 c^T term (DESIGN.md 2)
+        C = res['1'][0][li]
+        if rows:
+            C = C.permute(1, 0, 2, 3).reshape(M, B, B)
+        assert float((C.double() - Cref).abs().max()) <= 2e-6 * float(Cref.abs().max())
+        dref = Ws[li].double() @ Xd
+        assert float((res['1'][2][li].double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max())
+
+
 @pytest.mark.parametrize('with_res', [False, True])
 def test_fused_batchnorm_relu_matches_unfused(with_res, monkeypatch):
     """BatchNorm2d(..., residual=, relu=True) as one launch each way against the plain norm + torch add / relu
