@@ -281,11 +281,63 @@ __device__ __forceinline__ void member_tile(int per, int xcd_map, int& m, int& t
 // Split-precision variants of the centred Gram for interior shapes (B % 128 == 0, P % 16 == 0): same math, operands
 // split on the way into LDS (gemm_bf16x6.hpp).  SCHEME 0: three bf16 terms.  SCHEME 1: two fp16 terms of the centred
 // value scaled by s = 2^k, k from xmax[m] so that |x - sbar| * s <= 2 xmax s <= 2^14; the epilogue undoes s^2.
-// tile index within a member -> (I <= J).  HECKA_TILE_ORDER 1: the off-diagonal tiles first, the diagonal ones last
+// tile index within a member -> (I <= J).  HECKA_TILE_ORDER (compile time) - 0: row-major; 1: the off-diagonal tiles
+// (row-major) first, the diagonal ones last; 2: column-major; 3: the diagonal tiles first; 4 / 5: off-diagonal first,
+// column-major / by distance from the diagonal.  A diagonal tile loads half the rows and finishes early; with the long
+// tiles of a member issued together and the short ones behind them the all-layers launch of the bench runs 2 - 4 %
+// shorter than row-major (same box: 1634 -> 1580 us with order 1; on another 1595 -> 1564 with 5, 1575 with 4, 1590 with
+// 1; 3 and 2 lose to both).  Which tile a workgroup computes does not change any result.
 #ifndef HECKA_TILE_ORDER
-#define HECKA_TILE_ORDER 0
+#define HECKA_TILE_ORDER 5
 #endif
 __device__ __forceinline__ void tri_tile(int rem, int ntile, int& I, int& J) {
+  if (HECKA_TILE_ORDER == 2) {        // column-major: neighbours share the column panel
+    J = 0;
+    while (rem > J) {
+      rem -= J + 1;
+      ++J;
+    }
+    I = rem;
+    return;
+  }
+  if (HECKA_TILE_ORDER == 4 || HECKA_TILE_ORDER == 5) {   // off-diagonal tiles first (4: column-major, 5: by distance from the diagonal)
+    const int noff = ntile * (ntile - 1) / 2;
+    if (rem >= noff) {
+      I = J = rem - noff;
+      return;
+    }
+    if (HECKA_TILE_ORDER == 4) {
+      J = 1;
+      while (rem >= J) {
+        rem -= J;
+        ++J;
+      }
+      I = rem;
+    } else {
+      int d = 1;
+      while (rem >= ntile - d) {
+        rem -= ntile - d;
+        ++d;
+      }
+      I = rem;
+      J = rem + d;
+    }
+    return;
+  }
+  if (HECKA_TILE_ORDER == 3) {        // the diagonal tiles first
+    if (rem < ntile) {
+      I = J = rem;
+      return;
+    }
+    rem -= ntile;
+    I = 0;
+    while (rem >= ntile - 1 - I) {
+      rem -= ntile - 1 - I;
+      ++I;
+    }
+    J = I + 1 + rem;
+    return;
+  }
   if (HECKA_TILE_ORDER) {
     const int noff = ntile * (ntile - 1) / 2;
     if (rem >= noff) {
