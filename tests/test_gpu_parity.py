@@ -1040,7 +1040,8 @@ def test_multi_gram_split_k_matches_unsplit(dtype, monkeypatch):
         assert _relerr(g.numpy(), o.grad.numpy()) <= tol
 
 
-@pytest.mark.parametrize('M,B,dims,rows', [(64, 512, (1024, 512), 0), (8, 256, (2048, 256), 64), (16, 128, (96, 32), 0)])
+@pytest.mark.parametrize('M,B,dims,rows', [(64, 512, (1024, 512), 0), (8, 256, (2048, 256), 64), (16, 128, (96, 32), 0),
+                                           (2, 1024, (512, 256), 0), (3, 768, (256,), 256)])
 def test_k32_tile_equals_x6_tile_to_rounding(M, B, dims, rows, monkeypatch):
     """The 32-deep 16x16x32 tile (gemm_f16x3_k32.hpp: all-layers Gram, 256 x 256 dX launch) against the 16-deep 32x32x16 tile
     it replaces (HECKA_K32=0) on the same operands: the same two-term products in another summation order - C, cvec and
