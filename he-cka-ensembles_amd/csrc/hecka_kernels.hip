@@ -2986,6 +2986,20 @@ static __device__ __align__(256) float g_pairwise_scratch[kNoallocScratchFloats]
 constexpr int kMaxDevices = 64;
 static float* g_pairwise_scratch_ptr[kMaxDevices] = {};
 
+// set-up of the allocation-free entry point for the CURRENT device: looks up that device's copy of the array (once; two
+// threads racing here look up the same address).  Idempotent, allocates nothing.
+int hecka_noalloc_init(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return fail(HECKA_ELAUNCH, "%snoalloc_init: no current device (%lld)", "", (long long)dev);
+  if (__atomic_load_n(&g_pairwise_scratch_ptr[dev], __ATOMIC_ACQUIRE)) return HECKA_OK;
+  void* p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_pairwise_scratch));
+  if (e != hipSuccess || !p) return fail(HECKA_ELAUNCH, "%snoalloc_init: hipGetSymbolAddress failed (%lld)", "", (long long)e);
+  __atomic_store_n(&g_pairwise_scratch_ptr[dev], static_cast<float*>(p), __ATOMIC_RELEASE);
+  return HECKA_OK;
+}
+
 int hecka_pairwise_noalloc_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* stream) {
   clear_error();
   if (!Ca || !Cb || !S) return fail(HECKA_EINVAL, "pairwise_noalloc: null pointer%s");
@@ -2999,13 +3013,25 @@ int hecka_pairwise_noalloc_f32(const float* Ca, int Ma, const float* Cb, int Mb,
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
     return fail(HECKA_ELAUNCH, "%spairwise_noalloc: no current device (%lld)", "", dev);
+  if (stream) {    // the kernels run on the stream's GPU: its copy of the array is the one they must get
+    hipDevice_t sdev = -1;
+    if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(HECKA_EINVAL, "pairwise_noalloc: the stream's device cannot be determined%s");
+    }
+    if ((int)sdev != dev)
+      return fail(HECKA_EINVAL, "%spairwise_noalloc: the stream belongs to device %lld, which is not the current device", "",
+                  (long long)sdev);
+  }
   float* part = __atomic_load_n(&g_pairwise_scratch_ptr[dev], __ATOMIC_ACQUIRE);
-  if (!part) {     // set-up, once per device (two threads racing here look up the same address)
-    void* p = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_pairwise_scratch));
-    if (e != hipSuccess || !p) return fail(HECKA_ELAUNCH, "%spairwise_noalloc: hipGetSymbolAddress failed (%lld)", "", (long long)e);
-    part = static_cast<float*>(p);
-    __atomic_store_n(&g_pairwise_scratch_ptr[dev], part, __ATOMIC_RELEASE);
+  if (!part) {
+    // not set up by hecka_noalloc_init: do it here, unless the stream is capturing (a symbol lookup may load the code
+    // object, which is not a capturable operation)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(HECKA_EINVAL, "pairwise_noalloc: call hecka_noalloc_init() on this device before capturing%s");
+    if (int rc = hecka_noalloc_init()) return rc;
+    part = __atomic_load_n(&g_pairwise_scratch_ptr[dev], __ATOMIC_ACQUIRE);
   }
   // every slab element is written by the first stage before the second stage reads it: nothing has to start at zero,
   // whatever the previous call left in the array

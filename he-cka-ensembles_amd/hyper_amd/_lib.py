@@ -20,6 +20,7 @@ SIGNATURES = {
     'hecka_gram_center_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     'hecka_pairwise_workspace_bytes': (_sz, [_i, _i, _ll]),
     'hecka_pairwise_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
+    'hecka_noalloc_init': (_i, []),
     'hecka_pairwise_noalloc_f32': (_i, [_vp, _i, _vp, _i, _ll, _vp, _vp]),
     'hecka_head_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp]),
     'hecka_head_bwd_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _d, _d, _d, _i, _vp, _vp, _d, _vp, _vp]),

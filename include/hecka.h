@@ -93,11 +93,16 @@ int hecka_pairwise_f32(const float* Ca, int Ma, const float* Cb, int Mb, long lo
 /* hecka_pairwise_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc): the same kernels and the same result, bit for bit, but the split-K partial sums live in
  * an 8 MiB array built into the library (one copy per GPU, held until the process ends) instead of a caller workspace.
- * No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine; the first call on a device looks up
- * that device's copy of the array (hipGetSymbolAddress).  Shapes whose partial sums exceed 8 MiB
+ * No counterpart in the reference.  Calls no hipMalloc / hipFree / allocating routine.  Set-up: hecka_noalloc_init(), once
+ * per device with that device current, looks up the device's copy of the array (hipGetSymbolAddress; idempotent, no
+ * allocation).  A call on a device that was never set up does the set-up itself - except while `stream` is capturing,
+ * where it returns HECKA_EINVAL: call hecka_noalloc_init() (or make one ordinary call) on the device BEFORE capturing.
+ * `stream` must belong to the current device (checked; NULL = the current device's default stream): the kernels get the
+ * current device's array.  Shapes whose partial sums exceed 8 MiB
  * (hecka_pairwise_workspace_bytes(Ma, Mb, K) > 8 MiB - not the case for any Ma x Mb <= 64 x 192 or 128 x 128 with the
  * default split) return HECKA_EWORKSPACE: use hecka_pairwise_f32.  All calls on one GPU share that GPU's array, so two
  * calls that overlap on one GPU (different streams, different threads) race; calls on one stream are ordered. */
+int hecka_noalloc_init(void);
 int hecka_pairwise_noalloc_f32(const float* Ca, int Ma, const float* Cb, int Mb, long long K, float* S, void* stream);
 
 /* Pairwise head on the [Ma,Mb] matrix of inner products (rows = this GPU's members starting at global
