@@ -9,9 +9,12 @@ resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  At N = 1 the run checks itself: the loss and every layer's gradient of the timed
-workload are compared with the oracle evaluated in fp64 on the same tensors (`parity`), and the process exits with
-status 3 when either is off by more than rel 1e-5 (the JSON line is still printed)."""
+Prints ONE JSON line (rank 0).  The run checks itself: the loss and every layer's gradient of the timed workload are
+compared with the oracle evaluated in fp64 on the same tensors (`parity`), and the process exits with status 3 when
+either is off by more than rel 1e-5 (the JSON line is still printed).  At N > 1 every rank checks its member slice: against
+the unsharded hyper_amd evaluation of all 64 members run (untimed) on its own GPU, and rank 0 also against the fp64 oracle;
+the line then carries `rccl_ranks`, `collectives_per_eval`, `exchanged_bytes_per_rank_per_eval` and
+`exposed_wait_ms_per_eval` (how long the compute stream stood waiting for exchanged data, from HIP events around the waits)."""
 import argparse
 import json
 import os
@@ -226,14 +229,49 @@ def main():
     dt, per, loss, prof = timed(step, args.steps, args.warmup, profile=True)
     loss_val = float(loss.item())
     grads = [x.grad.detach().clone() for x in xs]
-    sent_per_eval = 0
+    sent_per_eval = coll_per_eval = 0
+    wait_ms = None
     if sharded:      # bytes this rank sends per evaluation (hyper_amd.parallel counts what it hands to the collectives)
         from hyper_amd import parallel
-        b0 = parallel.EXCHANGED_BYTES
+        b0, c0 = parallel.EXCHANGED_BYTES, parallel.COLLECTIVES
         step()
-        sent_per_eval = parallel.EXCHANGED_BYTES - b0
+        sent_per_eval, coll_per_eval = parallel.EXCHANGED_BYTES - b0, parallel.COLLECTIVES - c0
+        # exposed exchange time: HIP events on the compute stream around every wait for exchanged data, a few untimed evals
+        parallel.PROFILE = []
+        nprobe = 5
+        for _ in range(nprobe):
+            step()
+        torch.cuda.synchronize()
+        recs, parallel.PROFILE = parallel.PROFILE, None
+        wait_ms = sum(a.elapsed_time(b) for a, b in recs) / nprobe
 
     parity, bad = None, False
+    if sharded and not args.no_parity:
+        # every rank: its slice of the sharded result against the UNSHARDED evaluation of all members on its own GPU
+        full = make_feats(dev, slice(None))
+        fx = [f.requires_grad_(True) for f in full]
+        floss = build_model_kernel(CFG).to(dev)(None, OrderedDict((str(i), x) for i, x in enumerate(fx)), None, OrderedDict())
+        floss.backward()
+        pr = parity_record(loss_val, grads, float(floss.item()), [x.grad[members] for x in fx])
+        worst = torch.tensor([pr['loss_rel'], pr['grad_rel_max']], device=dev, dtype=torch.float64)
+        if dist is not None and world > 1:
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        parity = {'vs_unsharded_on_every_rank': {'loss_rel': float(worst[0]), 'grad_rel_max': float(worst[1])}, 'rtol': PARITY_RTOL}
+        bad = not (float(worst[0]) <= PARITY_RTOL and float(worst[1]) <= PARITY_RTOL)
+        for x in fx:
+            x.grad = None
+        if rank == 0:   # ... and rank 0 against the fp64 oracle on all members
+            ref_loss, ref_grads = oracle_fp64_on_gpu(CFG, fx)
+            po = parity_record(loss_val, grads, ref_loss, [g[members] for g in ref_grads])
+            parity.update(po, oracle='oracle/hecka_ref.py in fp64 on all 64 members, on rank 0\'s GPU; rank 0\'s member slice compared')
+            bad = bad or not (po['loss_rel'] <= PARITY_RTOL and po['grad_rel_max'] <= PARITY_RTOL)
+            del ref_grads
+        del full, fx, floss
+        torch.cuda.empty_cache()
+        if dist is not None and world > 1:     # every rank leaves with the same verdict
+            flag = torch.tensor([1.0 if bad else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            bad = bool(flag.item() > 0)
     if world == 1 and not sharded and not args.no_parity:
         ref_loss, ref_grads = oracle_fp64_on_gpu(CFG, xs)
         parity = dict(parity_record(loss_val, grads, ref_loss, ref_grads), rtol=PARITY_RTOL,
@@ -300,9 +338,12 @@ def main():
             'roofline': dict({'bound': 'mfma', 'kernel': kname, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                               'frac': ach / peak, 'avg_launch_ms': kms / max(len(prof['gram_bwd']), 1), 'traffic': traffic}, **hw),
         }
-        if world > 1:
+        if sharded:
             out['per_rank_ms_per_step'] = ms      # max over ranks (each rank runs M/world members)
+            out['rccl_ranks'] = world if os.environ.get('HECKA_BENCH_BACKEND', 'nccl') == 'nccl' else 0
+            out['collectives_per_eval'] = coll_per_eval
             out['exchanged_bytes_per_rank_per_eval'] = sent_per_eval
+            out['exposed_wait_ms_per_eval'] = wait_ms
         if parity is not None:
             out['parity'] = parity
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only

@@ -40,7 +40,7 @@ SIGNATURES = {
     'hecka_gram_center_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'hecka_wbound_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'hecka_colmean_x16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     'hecka_gram_center_multi_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
     'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'hecka_head_fwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -76,7 +76,11 @@ SIGNATURES = {
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'hecka_gram_bwd_multi_eligible': (_i, [_i, _i, _i, _vp, _i]),
-    'hecka_gram_bwd_multi_f32': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    'hecka_gram_bwd_multi_f32': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'hecka_config_reload': (None, []),
+    'hecka_blocked_rows_eligible': (_i, [_i, _ll, _i]),
+    'hecka_pairwise_self_blocked_f32': (_i, [_vp, _i, _i, _ll, _i, _vp, _vp, _sz, _vp]),
+    'hecka_combine_slice_blocked_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp, _vp]),
 }
 
 
@@ -100,6 +104,11 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def reload_config():
+    """Re-read the library's HECKA_* environment knobs (they are read once, at load time)."""
+    lib().hecka_config_reload()
 
 
 def check(rc, what):

@@ -227,10 +227,13 @@ def multi_gram_eligible(Xs):
     return B % 4 == 0 and get_gemm_mode() == 0 and os.environ.get('HECKA_RAGGED_X3') != '0'
 
 
-def centered_gram_multi(Xs, slice_rows=0):
+def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
     """[X_l [M,B,P_l]] -> [(C_l, cvec_l, xmax_l)]: the column-mean passes, then every layer's centred Gram in one
     launch, deepest layer first (no autograd).  slice_rows (a power of two dividing B; fp32 features): C_l comes as
-    [B / slice_rows, M, slice_rows, B] - the send order of the member-sharded exchange - instead of [M, B, B]."""
+    [B / slice_rows, M, slice_rows, B] - the send order of the member-sharded exchange - instead of [M, B, B].
+    one_buffer (with slice_rows): all layers are written into ONE buffer [B / slice_rows, L, M, slice_rows, B] - every
+    layer's rows for one destination rank contiguous, the send order of a single all_to_all_single for all layers;
+    returns (list, buffer), C_l being the view buffer[:, l]."""
     import ctypes
     L = _lib.lib()
     M, B = Xs[0].shape[0], Xs[0].shape[1]
@@ -243,7 +246,13 @@ def centered_gram_multi(Xs, slice_rows=0):
         raise RuntimeError('centered_gram_multi: all layers need one feature dtype')
     out = []
     cvec_all = torch.empty((len(Xs), M, B), device=dev, dtype=torch.float32)   # one tensor: the batched gamma stage reads it whole
-    C_all = torch.empty((len(Xs), M, B, B), device=dev, dtype=torch.float32)   # likewise for the batched pairwise stage
+    if one_buffer:
+        if not slice_rows:
+            raise RuntimeError('centered_gram_multi: one_buffer needs slice_rows')
+        Cbuf = torch.empty((B // slice_rows, len(Xs), M, slice_rows, B), device=dev, dtype=torch.float32)
+        C_all = [Cbuf[0, li] for li in range(len(Xs))]      # layer l's first slice block: base + l * M * slice_rows * B
+    else:
+        C_all = torch.empty((len(Xs), M, B, B), device=dev, dtype=torch.float32)   # likewise for the batched pairwise stage
     n = len(Xs)
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
     xmax_all = torch.empty((n, M), device=dev, dtype=torch.float32)
@@ -267,7 +276,10 @@ def centered_gram_multi(Xs, slice_rows=0):
     _lib.check(L.hecka_gram_center_multi_x16(
         n, ptrs([Xs[i] for i in order]), dt, ptrs([out[i][3] for i in order]), ptrs([out[i][2] for i in order]), M, B,
         Ps, ptrs([out[i][0] for i in order]), ptrs([out[i][1] for i in order]),
-        _p(ws) if ws is not None else None, nbytes, int(slice_rows), get_gemm_mode(), st), 'gram_center_multi')
+        _p(ws) if ws is not None else None, nbytes, int(slice_rows), len(Xs) * M if one_buffer else 0, get_gemm_mode(), st),
+        'gram_center_multi')
+    if one_buffer:
+        return [(Cbuf[:, li], cvec, xmax) for li, (C, cvec, xmax, _) in enumerate(out)], Cbuf
     if slice_rows:
         return [(C.view(B // slice_rows, M, slice_rows, B), cvec, xmax) for C, cvec, xmax, _ in out]
     return [(C, cvec, xmax) for C, cvec, xmax, _ in out]
@@ -393,9 +405,10 @@ def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
     return bool(_lib.lib().hecka_gram_bwd_multi_eligible(len(Xs), M, B, Ps, int(slice_rows)))
 
 
-def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
+def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0, slice_members=0):
     """[dX_l] = [W_l X_l] for all layers in one launch, deepest layer first.  slice_rows: W_l lies as
-    [B / slice_rows, M, slice_rows, B] (see centered_gram_multi)."""
+    [B / slice_rows, M, slice_rows, B] (see centered_gram_multi); slice_members = L * M when the W_l are the views
+    buffer[:, l] of ONE buffer [B / slice_rows, L, M, slice_rows, B] (only their first elements' addresses are used)."""
     import ctypes
     n = len(Xs)
     M, B = Xs[0].shape[0], Xs[0].shape[1]
@@ -408,7 +421,8 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.lib().hecka_gram_bwd_multi_f32(n, ptrs(Ws), ptrs(Xs), ptrs(wmaxs), ptrs(xmaxs), _gp(gate), M, B, Ps,
-                                                  ptrs(dXs), int(slice_rows), get_gemm_mode(), _stream()), 'gram_bwd_multi')
+                                                  ptrs(dXs), int(slice_rows), int(slice_members), get_gemm_mode(), _stream()),
+               'gram_bwd_multi')
     if PROFILE is not None:
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, sum(2.0 * M * B * B * X.shape[2] for X in Xs)))
@@ -494,6 +508,37 @@ def pairwise_self_batched(C_all):
     _lib.check(lib.hecka_pairwise_self_batched_f32(_p(C_all), Ln, M, K, _p(S_all), _p(ws), nbytes, _stream()),
                'pairwise_self_batched')
     return S_all
+
+
+# --- the small stages on the layouts of the member-sharded exchange (one all_to_all_single for all layers delivers a
+# rank's column slices as [source rank][layer][members of that rank][n]; include/hecka.h, hecka_*_blocked_f32) ---
+def blocked_eligible(M, n, blk_rows):
+    return bool(_lib.lib().hecka_blocked_rows_eligible(int(M), int(n), int(blk_rows))) and get_gemm_mode() == 0
+
+
+def pairwise_self_blocked(Cbuf):
+    """Cbuf [G, L, Ml, n] (G * Ml = 64 members) -> S_all [L, 64, 64]; bit-equal to pairwise_self_batched on [L, 64, n]."""
+    G, Ln, Ml, n = Cbuf.shape
+    M = G * Ml
+    lib = _lib.lib()
+    S_all = torch.empty((Ln, M, M), device=Cbuf.device, dtype=torch.float32)
+    nbytes = Ln * lib.hecka_pairwise_workspace_bytes(M, M, n)
+    ws = torch.empty((max(nbytes, 4) // 4,), device=Cbuf.device, dtype=torch.float32)
+    _lib.check(lib.hecka_pairwise_self_blocked_f32(_p(Cbuf), Ln, M, n, Ml, _p(S_all), _p(ws), nbytes, _stream()),
+               'pairwise_self_blocked')
+    return S_all
+
+
+def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag):
+    """Layers l0 .. l0 + Lc - 1 of Cbuf [G, Lin, Ml, n] combined with A_part [Lc, 64, 64] / gamma_part [Lc, 64, B] into
+    Ws [G, Lc, Ml, n] - the send order of the returning exchange for that group of layers."""
+    G, Lin, Ml, n = Cbuf.shape
+    Lc, Ma, Mb = A_part.shape
+    Ws = torch.empty((G, Lc, Ml, n), device=Cbuf.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_combine_slice_blocked_f32(_p(A_part), _p(Cbuf), _p(gamma_part), Lc, Lin, int(l0), Ma, Mb, B,
+                                                          n_start, n, Ml, int(bool(detach_diag)), _p(Ws), _stream()),
+               'combine_slice_blocked')
+    return Ws
 
 
 def combine_full(A, C, gamma, detach_diag):
@@ -812,9 +857,21 @@ def transformed_gram_backward(A, C, rmean, gdiag, hband, X, gspec, gate=None):
     st = _stream()
     rho = torch.empty((M, B), device=X.device, dtype=torch.float32)
     W = torch.empty((M, B, B), device=X.device, dtype=torch.float32)
-    dX = torch.empty_like(X)
     _lib.check(L.hecka_coef_gamma_f32(_p(A), _p(rmean), M, M, B, _p(rho), st), 'coef_gamma')
     _lib.check(L.hecka_combine_f32(_p(A), _p(C), _p(rho), M, M, B, 1, _p(W), None, st), 'combine')
+    return transformed_gram_bwd_w(W, C, rmean, gdiag, hband, X, gspec, gate)
+
+
+def transformed_gram_bwd_w(W, C, rmean, gdiag, hband, X, gspec, gate=None):
+    """The member-local end of transformed_gram_backward: W [M,B,B] = dK' + dK'^T (zero diagonal) of these members'
+    cossim / rbf Grams C -> dX.  W is overwritten (the transform's backward runs in place).  The member-sharded path
+    (hyper_amd/parallel.py) calls it on the rows of W that came back from the exchange."""
+    L = _lib.lib()
+    M, B, P = X.shape
+    st = _stream()
+    if not W.is_contiguous() or tuple(W.shape) != (M, B, B):
+        raise RuntimeError('transformed_gram_bwd_w: W must be a contiguous [M,B,B] tensor')
+    dX = torch.empty_like(X)
     _lib.check(L.hecka_gram_transform_bwd_f32(_p(W), _p(C), _p(rmean), _p(gdiag), _p(hband), M, B, gspec.kind, st),
                'gram_transform_bwd')
     _lib.check(L.hecka_gram_bwd_f32(_p(W), _p(X), None, None, _gp(gate), M, B, P, _p(dX), get_gemm_mode(), st), 'gram_bwd')

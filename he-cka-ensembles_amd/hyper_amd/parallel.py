@@ -33,11 +33,14 @@ import torch.distributed as dist
 
 
 EXCHANGED_BYTES = 0      # bytes this rank has SENT through the collectives below (bench.py reports it per evaluation)
+COLLECTIVES = 0          # collective launches this rank has issued (one batched exchange = one RCCL group = one launch)
+PROFILE = None           # bench.py: a list -> (event before, event after) around every wait on the compute stream
 
 
-def _sent(nbytes):
-    global EXCHANGED_BYTES
+def _sent(nbytes, launches=1):
+    global EXCHANGED_BYTES, COLLECTIVES
     EXCHANGED_BYTES += int(nbytes)
+    COLLECTIVES += int(launches)
 
 
 class _Done:
@@ -45,19 +48,97 @@ class _Done:
         return True
 
 
+class _Works:
+    """Several work handles waited for as one."""
+
+    def __init__(self, works, keep=None, after=None):
+        self.works, self.keep, self.after = list(works), keep, after
+
+    def wait(self):
+        prof = PROFILE is not None and torch.cuda.is_available()
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.after is not None:
+            self.after()
+            self.after = None
+        self.keep = None
+        if prof:
+            e1.record()
+            PROFILE.append((e0, e1))
+        return True
+
+
 def _staged(group, *ts):
     return dist.get_backend(group) == 'gloo' and any(t.is_cuda for t in ts)
 
 
-def _all_to_all(out, inp, out_splits, in_splits, group):
-    world = dist.get_world_size(group)
-    _sent(inp.numel() * inp.element_size() * (world - 1) // world)
-    if _staged(group, out, inp):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
-        out.copy_(o)
-        return _Done()
-    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=True)
+def exchange_mode():
+    """How the layers' segments travel when the blocked layouts (ONE all_to_all_single per exchange, _SlicedLayers) do not
+    apply.  HECKA_SHARD_EXCHANGE = a2a (default): one all_to_all_single per layer.  p2p: every layer's segments of an
+    exchange in ONE batched send / receive group (torch.distributed.batch_isend_irecv: on RCCL one ncclGroup, i.e. one
+    device launch whatever the number of layers, but 2 L (G - 1) Python-level operations on the host)."""
+    mode = os.environ.get('HECKA_SHARD_EXCHANGE', 'a2a')
+    if mode not in ('p2p', 'a2a'):
+        raise ValueError("HECKA_SHARD_EXCHANGE must be 'p2p' or 'a2a'")
+    return mode
+
+
+def _exchange(sends, recvs, send_splits, recv_splits, group):
+    """One exchange for a list of layers.  sends[l] / recvs[l]: flat contiguous buffers holding one segment per rank, in rank
+    order, of send_splits[g] / recv_splits[g] elements; segment g of sends[l] goes to rank g, segment s of recvs[l] comes
+    from rank s.  Returns a handle whose wait() orders the current stream behind the arrival of every segment."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    so = [0]
+    for n in send_splits:
+        so.append(so[-1] + n)
+    ro = [0]
+    for n in recv_splits:
+        ro.append(ro[-1] + n)
+    esz = sends[0].element_size()
+    sent = sum(so[-1] - send_splits[rank] for _ in sends) * esz
+    if exchange_mode() == 'a2a':
+        _sent(sent, len(sends))
+        works = []
+        for snd, rcv in zip(sends, recvs):
+            if _staged(group, snd, rcv):
+                o = torch.empty(rcv.shape, dtype=rcv.dtype)
+                dist.all_to_all_single(o, snd.cpu(), list(recv_splits), list(send_splits), group=group)
+                rcv.copy_(o)
+            else:
+                works.append(dist.all_to_all_single(rcv, snd, list(recv_splits), list(send_splits), group=group, async_op=True))
+        return _Works(works, keep=(sends, recvs))
+    _sent(sent, 1)
+    staged = _staged(group, *sends, *recvs)
+    ops, host = [], []
+    peer = (lambda g: g) if group is None else (lambda g: dist.get_global_rank(group, g))
+    for li, (snd, rcv) in enumerate(zip(sends, recvs)):
+        # this rank's own segment never leaves the device
+        if send_splits[rank]:
+            rcv[ro[rank]:ro[rank + 1]].copy_(snd[so[rank]:so[rank + 1]])
+        for g in range(world):
+            if g == rank:
+                continue
+            if send_splits[g]:
+                t = snd[so[g]:so[g + 1]]
+                ops.append(dist.P2POp(dist.isend, t.cpu() if staged else t, peer(g), group, tag=li))
+            if recv_splits[g]:
+                t = rcv[ro[g]:ro[g + 1]]
+                if staged:
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    host.append((t, h))
+                    t = h
+                ops.append(dist.P2POp(dist.irecv, t, peer(g), group, tag=li))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    after = None
+    if staged:
+        def after():
+            for dst, h in host:
+                dst.copy_(h)
+    return _Works(works, keep=(sends, recvs, ops), after=after)
 
 
 def _all_gather(out, inp, group):
@@ -67,7 +148,7 @@ def _all_gather(out, inp, group):
         dist.all_gather_into_tensor(o, inp.cpu(), group=group)
         out.copy_(o)
         return _Done()
-    return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
+    return _Works([dist.all_gather_into_tensor(out, inp, group=group, async_op=True)], keep=(out, inp))
 
 
 def _all_reduce(t, group):
@@ -89,88 +170,139 @@ def slice_bounds(n, world, granule=1):
     return [((g * units) // world) * q for g in range(world + 1)]
 
 
+def _a2a_equal(out, inp, group):
+    """ONE all_to_all_single with equal splits (the blocked layouts: every layer of an exchange in one buffer)."""
+    world = dist.get_world_size(group)
+    _sent(inp.numel() * inp.element_size() * (world - 1) // world, 1)
+    if _staged(group, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+        return _Done()
+    return _Works([dist.all_to_all_single(out, inp, group=group, async_op=True)], keep=(out, inp))
+
+
 class _SlicedLayers(torch.autograd.Function):
+    """Collectives per evaluation, whatever the number of layers (world > 1): forward ONE exchange (every layer's Gram
+    rows -> column slices) + ONE all-gather (every layer's partial inner products and centring vectors, summed locally in
+    rank order: bit-identical S on every rank); backward TWO exchanges (column slices of W -> rows: the deepest layer,
+    whose dX GEMM then runs while the other layers' slices are on the links, then the rest).
+
+    Blocked layouts (the bench's shapes: 64 members, slices of whole Gram rows; `backend.blocked_eligible`): each exchange
+    is ONE all_to_all_single.  The Gram epilogue writes all layers into one buffer [G][L][Ml][rows][B] - the send order - the
+    received [G][L][Ml][n] is read as it lies by the pairwise and combine kernels (member rows in blocks), combine writes
+    [G][L'][Ml][n] for each backward group and the dX GEMM reads the received [G][L'][Ml][rows][B]: no repacking anywhere.
+    Other shapes: the layers' segments travel per layer (`_exchange`) with repacking copies where a slice is not whole rows."""
+
     @staticmethod
     def forward(ctx, cfg, *feats):
-        backend, group, specs, weights, detach, reduce = cfg
+        backend, group, specs, weights, detach, reduce, gspecs = cfg
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         Ml, B = feats[0].shape[0], feats[0].shape[1]
         M, r0, N2 = Ml * world, rank * Ml, B * B
+        L = len(feats)
+        # everything below runs deepest layer first (the order of the all-layers launches and of the backward exchanges)
+        order = sorted(range(L), key=lambda i: -feats[i].shape[2])
+        feats = [feats[i].contiguous() for i in order]
+        specs, weights = [specs[i] for i in order], [weights[i] for i in order]
+        gspecs = [gspecs[i] for i in order] if gspecs is not None else None
         bounds = slice_bounds(N2, world, getattr(backend, 'SLICE_GRANULE', 1))
         ns = [bounds[g + 1] - bounds[g] for g in range(world)]
         n_r = ns[rank]
         even = all(n == n_r for n in ns)
-        feats = [X.contiguous() for X in feats]
+        for X in feats:
+            if X.shape[0] != Ml or X.shape[1] != B:
+                raise ValueError('every layer needs the same members and samples')
+        linear = gspecs is None
         multi = getattr(backend, 'multi_gram_eligible', None)
-        multi = multi is not None and multi(feats)
+        multi = linear and multi is not None and multi(feats)
         # slice-major Grams: when a slice is whole rows (a power of two of them) the Gram epilogue writes C straight in
-        # the all-to-all's send order [G, Ml, rows, B] and the dX GEMM reads W in the order it arrives - no repacking
+        # the exchange's send order [G, Ml, rows, B] and the dX GEMM reads W in the order it arrives - no repacking
         rows = n_r // B if (even and n_r % B == 0) else 0
         sliced = (world > 1 and multi and rows > 0 and rows & (rows - 1) == 0 and
                   feats[0].dtype in getattr(backend, 'SLICED_DTYPES', (torch.float32,)) and
                   hasattr(backend, 'gram_bwd_multi') and os.environ.get('HECKA_SHARD_REPACK', '0') != '1')
-        pre = (backend.centered_gram_multi(feats, slice_rows=rows) if sliced else backend.centered_gram_multi(feats)) if multi else None
-        slices, cvecs, xmaxs = [], [], []
-        # every layer's column slice in ONE buffer: the batched pairwise stage reads it whole
-        Cs_all = None
+        blocked = (sliced and hasattr(backend, 'blocked_eligible') and backend.blocked_eligible(M, n_r, Ml) and
+                   os.environ.get('HECKA_SHARD_BLOCKED', '1') != '0')
+        Cbuf = None
+        if blocked:
+            pre, Cbuf = backend.centered_gram_multi(feats, slice_rows=rows, one_buffer=True)      # [G, L, Ml, rows, B]
+        elif multi:
+            pre = backend.centered_gram_multi(feats, slice_rows=rows) if sliced else backend.centered_gram_multi(feats)
+        else:
+            pre = None
+        locs, fulls, cvecs, xmaxs, aux = [], [], [], [], []
         for li, X in enumerate(feats):
-            if X.shape[0] != Ml or X.shape[1] != B:
-                raise ValueError('every layer needs the same members and samples')
-            C, cvec, xmax = pre[li] if pre is not None else backend.centered_gram(X, True)
-            C2 = C.reshape(Ml, N2)
-            if world == 1:
-                slices.append((C2, _Done()))
-            else:
-                if sliced:
-                    send = C2.view(-1)
-                elif even:      # [Ml, G, n] -> [G, Ml, n] in one strided copy
-                    send = C2.view(Ml, world, n_r).permute(1, 0, 2).contiguous().view(-1)
-                else:
-                    send = torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)])
-                if Cs_all is None:
-                    Cs_all = torch.empty((len(feats), M, n_r), device=C.device, dtype=C.dtype)
-                Cs = Cs_all[li]
-                slices.append((Cs, _all_to_all(Cs.view(-1), send, [Ml * n_r] * world, [Ml * n for n in ns], group)))
+            if linear:
+                C, cvec, xmax = pre[li] if pre is not None else backend.centered_gram(X, True)
+                aux.append(None)
+            else:   # cossim / rbf: the row-wise transform of the raw Gram is local to a member; its row means play cvec's part
+                C, cvec, gdiag, hband = backend.transformed_gram(X, gspecs[li], True)
+                xmax = None
+                aux.append((C, cvec, gdiag, hband))
+            if not blocked:
+                locs.append(C.reshape(Ml, N2) if not sliced else C)
+            fulls.append(C)
             cvecs.append(cvec)
             xmaxs.append(xmax)
-        L = len(feats)
-        cv_loc = torch.stack(cvecs)                                              # [L, Ml, B]
+        cv_loc = getattr(backend, '_stacked', torch.stack)(cvecs)               # [L, Ml, B] (no copy after an all-layers launch)
+        if blocked:
+            # ONE all_to_all_single for all layers; the received [G][L][Ml][n_r] is read as it lies
+            Cs_all = torch.empty((world, L, Ml, n_r), device=Cbuf.device, dtype=Cbuf.dtype)
+            _a2a_equal(Cs_all.view(-1), Cbuf.view(-1), group).wait()
+            S_all = backend.pairwise_self_blocked(Cs_all)
+        else:
+            # every layer's column slice in ONE buffer [L, M, n_r]: the batched pairwise / combine stages read it whole
+            if world == 1:      # (the Grams of one all-layers launch already are one [L, M, B, B] buffer: no copy)
+                Cs_all, work = getattr(backend, '_stacked', torch.stack)(fulls).view(L, M, N2), _Done()
+            else:
+                Cs_all = torch.empty((L, M, n_r), device=locs[0].device, dtype=locs[0].dtype)
+                sends = []
+                for C2 in locs:
+                    if sliced:
+                        sends.append(C2.reshape(-1))
+                    elif even:      # [Ml, G, n] -> [G, Ml, n] in one strided copy
+                        sends.append(C2.view(Ml, world, n_r).permute(1, 0, 2).contiguous().view(-1))
+                    else:
+                        sends.append(torch.cat([C2[:, bounds[g]:bounds[g + 1]].reshape(-1) for g in range(world)]))
+                work = _exchange(sends, [Cs_all[li].view(-1) for li in range(L)], [Ml * n for n in ns], [Ml * n_r] * world, group)
+            work.wait()
+            elig = getattr(backend, 'pairwise_self_batched_eligible', None)
+            if n_r and elig is not None and elig(M, n_r):
+                S_all = backend.pairwise_self_batched(Cs_all)                        # one launch for all layers
+            else:
+                S_all = torch.stack([backend.pairwise_inner(Cs_all[li]) if n_r else
+                                     torch.zeros((M, M), device=Cs_all.device, dtype=Cs_all.dtype) for li in range(L)])   # [L, M, M]
         if world == 1:
             cv_all = cv_loc
         else:
-            raw = torch.empty((world, L, Ml, B), device=cv_loc.device, dtype=cv_loc.dtype)
-            _all_gather(raw.view(-1), cv_loc.view(-1), group).wait()
-            cv_all = raw.permute(1, 0, 2, 3).reshape(L, M, B).contiguous()
-        for _, work in slices:
-            work.wait()
-        elig = getattr(backend, 'pairwise_self_batched_eligible', None)
-        if world > 1 and elig is not None and elig(M, n_r):
-            S_all = backend.pairwise_self_batched(Cs_all)                        # one launch for all layers
-        else:
-            S_all = torch.stack([backend.pairwise_inner(Cs) if n_r else
-                                 torch.zeros((M, M), device=Cs.device, dtype=Cs.dtype) for Cs, _ in slices])   # [L, M, M]
-        if world > 1:
-            _all_reduce(S_all, group)
-        total, saved, scales = None, [], []
+            # ONE all-gather carries every rank's partial S and its members' centring vectors; the partial sums are
+            # added in rank order on every rank, so S (and everything derived from it) is bit-identical everywhere
+            nS, nc = L * M * M, L * Ml * B
+            pack = torch.cat([S_all.reshape(-1), cv_loc.reshape(-1).to(S_all.dtype)])
+            raw = torch.empty((world, nS + nc), device=pack.device, dtype=pack.dtype)
+            _all_gather(raw.view(-1), pack, group).wait()
+            S_all = torch.sum(raw[:, :nS], dim=0).view(L, M, M)      # (one kernel; the same reduction order on every rank)
+            cv_all = raw[:, nS:].reshape(world, L, Ml, B).permute(1, 0, 2, 3).reshape(L, M, B).contiguous().to(cv_loc.dtype)
+        scales = []
         for spec, wl in zip(specs, weights):
             count = (M * (M - 1) if spec.remove_diag else M * M) if reduce == 'mean' else 1
             scales.append(float(wl) / count if count else float('nan'))
         batched = len(specs) <= 16 and all(hasattr(backend, f) for f in
                                            ('head_forward_batched', 'head_backward_batched', 'coef_gamma_batched'))
         nsq_all = torch.diagonal(S_all, dim1=1, dim2=2).contiguous()
+        total = None
         if batched:                 # one head launch for all layers
             total = backend.head_forward_batched(S_all, nsq_all, 0, specs, scales).sum()
-        for li, (X, spec) in enumerate(zip(feats, specs)):
-            S, nsq = S_all[li], nsq_all[li]
-            if not batched:
-                _, part = backend.head_forward(S, nsq, 0, spec, scales[li])
+        else:
+            for li, spec in enumerate(specs):
+                _, part = backend.head_forward(S_all[li], nsq_all[li], 0, spec, scales[li])
                 total = part if total is None else total + part
-            saved.append((X, slices[li][0], cv_all[li], S, nsq, spec, scales[li], xmaxs[li]))
-        ctx.batch = (S_all, nsq_all, cv_all, specs, scales) if batched else None
-        ctx.saved, ctx.backend, ctx.group, ctx.detach = saved, backend, group, detach
+        ctx.feats, ctx.xmaxs, ctx.aux, ctx.order = feats, xmaxs, aux, order
+        ctx.state = (Cs_all, S_all, nsq_all, cv_all, specs, scales, batched)
+        ctx.backend, ctx.group, ctx.detach, ctx.gspecs = backend, group, detach, gspecs
         ctx.geom = (world, rank, Ml, B, bounds, ns)
-        ctx.sliced = rows if sliced else 0
-        ctx.Cs_all = Cs_all
+        ctx.sliced, ctx.blocked = (rows if sliced else 0), blocked
         ctx.gate = getattr(backend, 'current_gate', lambda: None)()     # ops.grad_gate: a masked NaN term gives dX = 0
         ctx.mode = getattr(backend, 'get_gemm_mode', lambda: None)()
         return total.clone()
@@ -186,85 +318,120 @@ class _SlicedLayers(torch.autograd.Function):
         be, group = ctx.backend, ctx.group
         world, rank, Ml, B, bounds, ns = ctx.geom
         r0, n_r, N2 = rank * Ml, ns[rank], B * B
+        Cs_all, S_all, nsq_all, cv_all, specs, scales, batched = ctx.state
+        feats, xmaxs, linear = ctx.feats, ctx.xmaxs, ctx.gspecs is None
+        L, M = len(feats), Ml * world
+        even = all(n == n_r for n in ns)
         dloss = dloss.contiguous().float() if dloss.is_cuda else dloss.contiguous()
-        pending = []
-        Ws_all = wmax_all = None
-        if ctx.batch is not None:   # one head_bwd and one gamma launch for all layers
-            S_all, nsq_all, cv_stack, specs, scales = ctx.batch
+        detach = ctx.detach if linear else True      # the diagonal of a cossim / rbf Gram carries no gradient
+        # the [M, M]-sized stages for all layers (the same on every rank)
+        if batched:
             A_all = be.head_backward_batched(S_all, nsq_all, 0, specs, dloss, scales)
-            gamma_all = be.coef_gamma_batched(A_all, cv_stack)
-            if world > 1 and ctx.Cs_all is not None and hasattr(be, 'combine_slice_batched'):   # ... and one combine launch
-                Ws_all = be.combine_slice_batched(A_all, ctx.Cs_all, gamma_all, B, bounds[rank], ctx.detach)
-            if hasattr(be, 'wbound_batched') and all(s[7] is not None for s in ctx.saved):
+            gamma_all = be.coef_gamma_batched(A_all, cv_all)
+        else:
+            A_all = torch.stack([be.head_backward(S_all[li], nsq_all[li], 0, specs[li], dloss, scales[li]) for li in range(L)])
+            gamma_all = torch.stack([be.coef_gamma(A_all[li], cv_all[li]) for li in range(L)])
+        wmaxs = [None] * L
+        if linear and all(x is not None for x in xmaxs):
+            if hasattr(be, 'wbound_batched'):
                 wmax_all = be.wbound_batched(A_all[:, r0:r0 + Ml].contiguous(), nsq_all, gamma_all[:, r0:r0 + Ml].contiguous())
-        # exchanges are issued deepest layer first: its W arrives first and its dX GEMM (half the flops at the bench's
-        # widths) runs while the other layers' slices are still on the links
-        order = sorted(range(len(ctx.saved)), key=lambda i: -ctx.saved[i][0].shape[2])
-        for li in order:
-            X, Cs, cv_all, S, nsq, spec, scale, xmax = ctx.saved[li]
-            if ctx.batch is not None:
-                A, gamma = A_all[li], gamma_all[li]
-            else:
-                A = be.head_backward(S, nsq, 0, spec, dloss, scale)              # [M, M], the same on every rank
-                gamma = be.coef_gamma(A, cv_all)                                 # [M, B]
-            Ws = Ws_all[li] if Ws_all is not None else be.combine_slice(A, Cs, gamma, B, bounds[rank], ctx.detach)   # [M, n_r]
-            if world == 1:
-                recv, work = Ws, _Done()
-            else:
-                recv = torch.empty((Ml * N2,), device=Ws.device, dtype=Ws.dtype)
-                work = _all_to_all(recv, Ws.view(-1), [Ml * n for n in ns], [Ml * n_r] * world, group)
-            wmax = None
-            if wmax_all is not None:
-                wmax = wmax_all[li]
-            elif xmax is not None and hasattr(be, 'wbound'):
-                wmax = be.wbound(A[r0:r0 + Ml].contiguous(), nsq, gamma[r0:r0 + Ml].contiguous())
-            pending.append((X, recv, work, wmax, xmax))
+                wmaxs = [wmax_all[li] for li in range(L)]
+            elif hasattr(be, 'wbound'):
+                wmaxs = [be.wbound(A_all[li, r0:r0 + Ml].contiguous(), nsq_all[li], gamma_all[li, r0:r0 + Ml].contiguous())
+                         for li in range(L)]
+        # layers are in depth order: the deepest layer's slices travel first, and its dX GEMM (half the flops at the
+        # bench's widths) runs while the other layers' slices are still on the links
+        split = world > 1 and L >= 3 and os.environ.get('HECKA_SHARD_BWD_SPLIT', '1') != '0'
+        parts = [[0], list(range(1, L))] if split else [list(range(L))]
         gate = (ctx.gate,) if ctx.gate is not None else ()
+        grads = [None] * L
 
-        def in_layer_order(grads):      # pending (and grads) are in `order`; autograd wants the layers' own order
-            out = [None] * len(grads)
-            for pos, li in enumerate(order):
+        def finish():
+            out = [None] * L
+            for pos, li in enumerate(ctx.order):
                 out[li] = grads[pos]
             return (None,) + tuple(out)
-        if ctx.sliced and be.gram_bwd_multi_eligible([p[1] for p in pending], [p[0] for p in pending], [p[3] for p in pending],
-                                                      [p[4] for p in pending], ctx.sliced):
-            # W stays as it arrived, [G, Ml, rows, B]: the dX launches read it in that order.  Two launches when there is
-            # an exchange to hide: the deepest layer as soon as its slices are in, the rest in one launch behind it
-            cut = 1 if (world > 1 and len(pending) >= 3 and os.environ.get('HECKA_SHARD_BWD_SPLIT', '1') != '0') else len(pending)
-            grads = []
-            for part in (pending[:cut], pending[cut:]):
-                if not part:
-                    continue
-                for p in part:
-                    p[2].wait()
-                grads += be.gram_bwd_multi([p[1] for p in part], [p[0] for p in part], [p[3] for p in part],
-                                           [p[4] for p in part], *gate, slice_rows=ctx.sliced)      # (one layer is a valid launch)
-            return in_layer_order(grads)
-        Wl = []
-        for X, recv, work, wmax, xmax in pending:
-            work.wait()
+
+        if ctx.blocked:
+            # per group: ONE combine launch writing the send order [G][L'][Ml][n_r], ONE all_to_all_single, and the dX
+            # launch reading the received [G][L'][Ml][rows][B] as it lies
+            pend = []
+            for part in parts:
+                l0, Lc = part[0], len(part)
+                Ws = be.combine_slice_blocked(A_all[l0:l0 + Lc], Cs_all, gamma_all[l0:l0 + Lc], l0, B, bounds[rank], detach)
+                Wr = torch.empty((world, Lc, Ml, ctx.sliced, B), device=Ws.device, dtype=Ws.dtype)
+                pend.append((part, Wr, _a2a_equal(Wr.view(-1), Ws.view(-1), group)))
+            for part, Wr, work in pend:
+                work.wait()
+                out = be.gram_bwd_multi([Wr[:, k] for k in range(len(part))], [feats[li] for li in part],
+                                        [wmaxs[li] for li in part], [xmaxs[li] for li in part], *gate,
+                                        slice_rows=ctx.sliced, slice_members=len(part) * Ml)
+                for li, g in zip(part, out):
+                    grads[li] = g
+            return finish()
+
+        # every layer's slice of W, then the exchanges
+        if not n_r:
+            Ws_all = torch.empty((L, M, 0), device=Cs_all.device, dtype=Cs_all.dtype)
+        elif hasattr(be, 'combine_slice_batched'):
+            Ws_all = be.combine_slice_batched(A_all, Cs_all, gamma_all, B, bounds[rank], detach)        # [L, M, n_r]
+        else:
+            Ws_all = torch.stack([be.combine_slice(A_all[li], Cs_all[li], gamma_all[li], B, bounds[rank], detach) for li in range(L)])
+        recv = {}
+        works = []
+        for part in parts:
             if world == 1:
-                W = recv
-            elif all(n == n_r for n in ns):      # [G, Ml, n] -> [Ml, G, n] in one strided copy
-                W = recv.view(world, Ml, n_r).permute(1, 0, 2).contiguous()
+                for li in part:
+                    recv[li] = Ws_all[li].reshape(-1)
+                works.append(_Done())
+                continue
+            for li in part:
+                recv[li] = torch.empty((Ml * N2,), device=Ws_all.device, dtype=Ws_all.dtype)
+            works.append(_exchange([Ws_all[li].reshape(-1) for li in part], [recv[li] for li in part],
+                                   [Ml * n_r] * world, [Ml * n for n in ns], group))
+
+        def rows_of(li):     # the local members' W [Ml, B, B] from the segments as they arrived ([G][Ml][n_g])
+            r = recv[li]
+            if world == 1:
+                return r.view(Ml, B, B)
+            if even:         # [G, Ml, n] -> [Ml, G, n] in one strided copy
+                return r.view(world, Ml, n_r).permute(1, 0, 2).contiguous().view(Ml, B, B)
+            W = torch.empty((Ml, N2), device=r.device, dtype=r.dtype)
+            off = 0
+            for g in range(world):
+                W[:, bounds[g]:bounds[g + 1]] = r[off:off + Ml * ns[g]].view(Ml, ns[g])
+                off += Ml * ns[g]
+            return W.view(Ml, B, B)
+
+        for part, work in zip(parts, works):
+            work.wait()
+            if not linear:
+                for li in part:
+                    C, rmean, gdiag, hband = ctx.aux[li]
+                    grads[li] = be.transformed_gram_bwd_w(rows_of(li), C, rmean, gdiag, hband, feats[li], ctx.gspecs[li], *gate)
+                continue
+            Xs, wm, xm = [feats[li] for li in part], [wmaxs[li] for li in part], [xmaxs[li] for li in part]
+            multi = getattr(be, 'gram_bwd_multi_eligible', None)
+            if ctx.sliced and multi is not None and multi([recv[li] for li in part], Xs, wm, xm, ctx.sliced):
+                # W stays as it arrived, [G, Ml, rows, B]: the dX launch reads it in that order (one layer is a valid launch)
+                out = be.gram_bwd_multi([recv[li] for li in part], Xs, wm, xm, *gate, slice_rows=ctx.sliced)
             else:
-                W = torch.empty((Ml, N2), device=recv.device, dtype=recv.dtype)
-                off = 0
-                for g in range(world):
-                    W[:, bounds[g]:bounds[g + 1]] = recv[off:off + Ml * ns[g]].view(Ml, ns[g])
-                    off += Ml * ns[g]
-            Wl.append(W.view(Ml, B, B))
-        multi = getattr(be, 'gram_bwd_multi_eligible', None)
-        if multi is not None and multi(Wl, [p[0] for p in pending], [p[3] for p in pending], [p[4] for p in pending]):
-            return in_layer_order(be.gram_bwd_multi(Wl, [p[0] for p in pending], [p[3] for p in pending],
-                                                    [p[4] for p in pending], *gate))
-        return in_layer_order([be.gram_bwd_w(W, X, wmax, xmax, *gate) for W, (X, _, _, wmax, xmax) in zip(Wl, pending)])
+                Wl = [rows_of(li) for li in part]
+                if multi is not None and multi(Wl, Xs, wm, xm):
+                    out = be.gram_bwd_multi(Wl, Xs, wm, xm, *gate)
+                else:
+                    out = [be.gram_bwd_w(W, X, a, b, *gate) for W, X, a, b in zip(Wl, Xs, wm, xm)]
+            for li, g in zip(part, out):
+                grads[li] = g
+        return finish()
 
 
 class _GatheredLayers(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, *feats):
-        backend, group, specs, weights, detach, reduce = cfg
+        backend, group, specs, weights, detach, reduce, gspecs = cfg
+        if gspecs is not None:
+            raise NotImplementedError("cossim / rbf layers are sharded by the 'slice' scheme only")
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         Ml = feats[0].shape[0]
         M, r0 = Ml * world, rank * Ml
@@ -327,19 +494,24 @@ def shard_mode(backend):
     return mode
 
 
-def sharded_layers_loss(feats, specs, weights, detach_diag=True, reduce='mean', group=None, backend=None):
+def sharded_layers_loss(feats, specs, weights, detach_diag=True, reduce='mean', group=None, backend=None, gspecs=None):
     """Global `model_layers` loss from this rank's member slice of every layer's features.
-    feats: list of [M/G, B, P_l]; specs: one ops.HeadSpec per layer; weights: per-layer floats."""
+    feats: list of [M/G, B, P_l]; specs: one ops.HeadSpec per layer; weights: per-layer floats; gspecs: one ops.GramSpec
+    per layer for cossim / rbf Grams (all layers; None = centred linear Grams)."""
     if backend is None:
         from . import ops as backend
     if reduce not in ('mean', 'sum'):
         raise ValueError("the sharded loss supports reduction 'mean' or 'sum'")
-    if hasattr(backend, '_features'):      # 16-bit features: native where the kernels take them, else the exact up-cast
+    if gspecs is not None:
+        if hasattr(backend, '_features_f32'):
+            feats = [backend._features_f32(X) for X in feats]
+    elif hasattr(backend, '_features'):      # 16-bit features: native where the kernels take them, else the exact up-cast
         feats = [backend._features(X) for X in feats]
         if len({X.dtype for X in feats}) > 1:
             feats = [backend._features_f32(X) for X in feats]
-    fn = _SlicedLayers if shard_mode(backend) == 'slice' else _GatheredLayers
-    return fn.apply((backend, group, list(specs), list(weights), bool(detach_diag), reduce), *feats)
+    fn = _SlicedLayers if (gspecs is not None or shard_mode(backend) == 'slice') else _GatheredLayers
+    return fn.apply((backend, group, list(specs), list(weights), bool(detach_diag), reduce,
+                     list(gspecs) if gspecs is not None else None), *feats)
 
 
 class ShardedModelLayersKernel(torch.nn.Module):
@@ -358,14 +530,24 @@ class ShardedModelLayersKernel(torch.nn.Module):
         k.layer_weighting.save_total(len(feats))
         kerns = list(k.layer_kernel) if k.different_kernels else [k.layer_kernel] * len(feats)
         specs = [kk._spec() for kk in kerns]
-        if any(s is None for s in specs):
-            raise NotImplementedError('member sharding needs linear, centred, non-learnable he/cka layer kernels')
-        detach = {kk.feature_kernel.detach_diag for kk in kerns}
-        if len(detach) != 1:
-            raise NotImplementedError('member sharding needs one detach_diag setting for all layers')
+        gspecs = [kk.feature_kernel.gram_spec() for kk in kerns]
+        if any(s is None for s in specs) or any(g is None for g in gspecs):
+            raise NotImplementedError('member sharding needs centred, non-learnable he / cka layer kernels on linear, '
+                                      'cossim or rbf Grams')
         weights = [float(k.layer_weighting.get_weight(i, len(feats))) for i in range(len(feats))]
         xs = [kerns[i].feature_kernel.flatten(f) for i, f in enumerate(feats.values())]
-        return sharded_layers_loss(xs, specs, weights, detach.pop(), k.reduction, self.group, self.backend)
+        # one call (= one set of collectives) per kind of Gram and detach_diag setting; a shipped config has one
+        groups = {}
+        for i, (kk, g) in enumerate(zip(kerns, gspecs)):
+            lin = g.kind == 0        # ops.GRAM_LINEAR
+            groups.setdefault((lin, bool(kk.feature_kernel.detach_diag) if lin else True), []).append(i)
+        total = None
+        for (lin, detach), idx in groups.items():
+            part = sharded_layers_loss([xs[i] for i in idx], [specs[i] for i in idx], [weights[i] for i in idx], detach,
+                                       k.reduction, self.group, self.backend,
+                                       None if lin else [gspecs[i] for i in idx])
+            total = part if total is None else total + part
+        return total
 
 
 class _ScaledLoss(torch.nn.Module):

@@ -29,6 +29,9 @@ extern "C" {
 
 int hecka_version(void);
 const char* hecka_last_error(void);
+/* The library reads its (few, optional) HECKA_* environment knobs once, at load time - never on the call path;
+ * hecka_config_reload() re-reads them (tests that switch a knob inside one process).  INTEGRATION.md 6 lists them. */
+void hecka_config_reload(void);
 
 /* Arithmetic of the two large GEMMs - the `gemm_mode` argument of hecka_gram_center_*, hecka_gram_bwd_*.  No counterpart
  * in the reference (torch.bmm picks its own algorithm).  It is a per-call argument: the library holds no process-wide
@@ -160,6 +163,21 @@ int hecka_coef_gamma_batched_f32(const float* A, const float* cvec, int L, int M
  * shape the LDS-tiled one with the layer in blockIdx.y. */
 int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long K, float* S_all, void* ws,
                                     size_t ws_bytes, void* stream);
+/* The same two stages on the layouts of the member-sharded exchange (hyper_amd/parallel.py; no counterpart in the reference,
+ * which scales with DDP over samples, hyper/experiments/training.py:686-695): one all_to_all_single for ALL layers delivers
+ * a rank's column slices as [source rank][layer][members of that rank][n] - the 64 member rows of a layer lie in blocks of
+ * blk_rows rows.  hecka_blocked_rows_eligible(M, n, blk_rows): M == 64, n % 64 == 0, blk_rows in {8, 16, 32, 64} (the
+ * streaming kernels; callers repack otherwise).
+ * hecka_pairwise_self_blocked_f32: C_all [M / blk_rows][L][blk_rows][K] -> S_all [L][M][M], bit-equal to the standard call.
+ * hecka_combine_slice_blocked_f32: Cs_all [Mb / blk_rows][Lin][blk_rows][n] of which the layers l0 .. l0 + L - 1 are
+ * combined (A_all [L,Ma,Mb], gamma_all [L,Ma,B] hold those L layers) into Ws_all [Ma / blk_rows][L][blk_rows][n] - the send
+ * order of the returning all_to_all_single for that group of layers. */
+int hecka_blocked_rows_eligible(int M, long long n, int blk_rows);
+int hecka_pairwise_self_blocked_f32(const float* C_all, int L, int M, long long K, int blk_rows, float* S_all, void* ws,
+                                    size_t ws_bytes, void* stream);
+int hecka_combine_slice_blocked_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Lin, int l0,
+                                    int Ma, int Mb, int B, long long n_start, long long n_count, int blk_rows,
+                                    int detach_diag, float* Ws_all, void* stream);
 int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamma, int L, int Ma, int Mb, int B,
                              float* wbound, void* stream);
 
@@ -377,11 +395,15 @@ int hecka_colmean_x16(const void* X, int dtype, int M, int B, int P, float* sbar
  * partial Grams in ws and sums them in a fixed order - every stage of the epilogue is linear in the k range.
  * slice_rows (hecka_gram_center_multi_x16, fp32 features): 0 = C[l] is [M,B,B]; a power of two dividing B = C[l] is
  * written as [B / slice_rows][M][slice_rows][B], the send order of the member-sharded all-to-all (hyper_amd/parallel.py)
- * - no repacking copy between the Gram and the exchange; hecka_gram_bwd_multi_f32 reads W in the same order. */
+ * - no repacking copy between the Gram and the exchange; hecka_gram_bwd_multi_f32 reads W in the same order.
+ * slice_members (with slice_rows; 0 = M): member rows per slice block.  With slice_members = L * M and C[l] = base +
+ * l * M * slice_rows * B the L layers share ONE buffer [B / slice_rows][L][M][slice_rows][B]: every layer's rows for one
+ * destination rank are contiguous, so the member-sharded exchange is a single all_to_all_single for all layers. */
 size_t hecka_gram_center_multi_workspace_bytes(int L, int M, int B, const int* P);
 int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const float* const* sbar,
                                 const float* const* xmax, int M, int B, const int* P, float* const* C,
-                                float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int gemm_mode, void* stream);
+                                float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int slice_members, int gemm_mode,
+                                void* stream);
 int hecka_gram_bwd_x16(const float* W, const void* X, int dtype, const float* wmax, const float* xmax, const float* gate,
                        int M, int B, int P, void* dX, int gemm_mode, void* stream);
 
@@ -400,12 +422,13 @@ int hecka_gram_bwd_f32(const float* W, const float* X, const float* wmax, const 
  * 446-478): a layer alone leaves the tail of its last scheduling round idle, and a member shard's small layers do not
  * fill the GPU.  f16x3 only (HECKA_GEMM_AUTO, wmax and xmax required), B <= 1024, B % 4 == 0; ragged B / P as in
  * hecka_gram_bwd_f32.  slice_rows: 0, or a power of two dividing B - W then lies as the member-sharded all-to-all
- * delivers it, [B / slice_rows][M][slice_rows][B] (no repacking copy).  hecka_gram_bwd_multi_eligible says whether the
- * call applies; callers use per-layer hecka_gram_bwd_f32 otherwise. */
+ * delivers it, [B / slice_rows][M][slice_rows][B] (no repacking copy); slice_members as for hecka_gram_center_multi_x16
+ * (the L layers of one exchange in ONE buffer [B / slice_rows][L][M][slice_rows][B], W[l] = base + l * M * slice_rows * B).
+ * hecka_gram_bwd_multi_eligible says whether the call applies; callers use per-layer hecka_gram_bwd_f32 otherwise. */
 int hecka_gram_bwd_multi_eligible(int L, int M, int B, const int* P, int slice_rows);
 int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X, const float* const* wmax,
                              const float* const* xmax, const float* gate, int M, int B, const int* P, float* const* dX,
-                             int slice_rows, int gemm_mode, void* stream);
+                             int slice_rows, int slice_members, int gemm_mode, void* stream);
 
 #ifdef __cplusplus
 }

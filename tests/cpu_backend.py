@@ -105,7 +105,16 @@ def multi_gram_eligible(Xs):
     return _multi() and len(Xs) >= 2
 
 
-def centered_gram_multi(Xs, slice_rows=0):
+def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
+    if one_buffer:      # [G, L, M, rows, B]: every layer's rows for one destination rank contiguous
+        CALLS['gram_multi_one_buffer'] = CALLS.get('gram_multi_one_buffer', 0) + 1
+        per = []
+        for X in Xs:
+            C, c, xmax = centered_gram(X, True)
+            M, B = C.shape[0], C.shape[1]
+            per.append((C.view(M, B // slice_rows, slice_rows, B).permute(1, 0, 2, 3), c, xmax))
+        buf = torch.stack([p[0] for p in per], dim=1).contiguous()
+        return [(buf[:, li], c, xmax) for li, (_, c, xmax) in enumerate(per)], buf
     CALLS['gram_multi_sliced' if slice_rows else 'gram_multi'] = CALLS.get('gram_multi_sliced' if slice_rows else 'gram_multi', 0) + 1
     out = []
     for X in Xs:
@@ -150,7 +159,26 @@ def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
     return _multi()
 
 
-def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
+def blocked_eligible(M, n, blk_rows):
+    return os.environ.get('CPU_BACKEND_BLOCKED') == '1'
+
+
+def pairwise_self_blocked(Cbuf):
+    G, L, Ml, n = Cbuf.shape
+    CALLS['pairwise_blocked'] = CALLS.get('pairwise_blocked', 0) + 1
+    return pairwise_self_batched(Cbuf.permute(1, 0, 2, 3).reshape(L, G * Ml, n))
+
+
+def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag):
+    G, Lin, Ml, n = Cbuf.shape
+    Lc = A_part.shape[0]
+    CALLS['combine_blocked'] = CALLS.get('combine_blocked', 0) + 1
+    Cs = Cbuf[:, l0:l0 + Lc].permute(1, 0, 2, 3).reshape(Lc, G * Ml, n)
+    Ws = torch.stack([combine_slice(A, C, g, B, n_start, detach_diag) for A, C, g in zip(A_part, Cs, gamma_part)])
+    return Ws.view(Lc, G, Ml, n).permute(1, 0, 2, 3).contiguous()
+
+
+def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0, slice_members=0):
     CALLS['bwd_multi_sliced' if slice_rows else 'bwd_multi'] = CALLS.get('bwd_multi_sliced' if slice_rows else 'bwd_multi', 0) + 1
     out = []
     for W, X in zip(Ws, Xs):
@@ -159,3 +187,41 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0):
             W = W.reshape(B // slice_rows, M, slice_rows, B).permute(1, 0, 2, 3).reshape(M, B, B)
         out.append(gram_bwd_w(W.reshape(M, B, B), X))
     return out
+
+
+# ---- cossim / rbf layers of the sliced scheme: the member-local transform stages (ops.transformed_gram /
+# ops.transformed_gram_bwd_w) restated with torch autograd on the CPU
+def _kprime(X, gspec, hband=None):
+    G = X @ X.transpose(1, 2)
+    g = torch.diagonal(G, dim1=1, dim2=2)
+    if gspec.kind == 1:                                  # cossim (hyper/diversity/kernels.py:145-169)
+        return G / torch.sqrt(g.unsqueeze(2) * g.unsqueeze(1)), g, hband
+    d = -2.0 * G + g.unsqueeze(2) + g.unsqueeze(1)        # rbf (kernels.py:198-286), bandwidth without gradient
+    if hband is None:
+        with torch.no_grad():
+            B = X.shape[1]
+            if gspec.median:
+                hband = torch.stack([gspec.param * d[m].median() / (2.0 * np.log(B + 1.0)) for m in range(X.shape[0])])
+            else:
+                hband = torch.full((X.shape[0],), gspec.param ** 2, dtype=X.dtype)
+    return torch.exp(-d / (2.0 * hband.view(-1, 1, 1))), g, hband
+
+
+def transformed_gram(X, gspec, center, out=None):
+    with torch.no_grad():
+        K, g, hband = _kprime(X.double(), gspec)
+        rmean = K.mean(dim=2) if center else torch.zeros(K.shape[:2], dtype=K.dtype)
+        C = K - rmean.unsqueeze(2)
+    if hband is None:
+        hband = torch.zeros(X.shape[0], dtype=torch.float64)
+    return C.contiguous(), rmean.contiguous(), g.contiguous(), hband
+
+
+def transformed_gram_bwd_w(W, C, rmean, gdiag, hband, X, gspec, gate=None):
+    # W = dK' + dK'^T with a zero diagonal; K'(X) is symmetric, so <W / 2, K'(X)> has the gradient dK' would give
+    CALLS['transform_bwd'] = CALLS.get('transform_bwd', 0) + 1
+    with torch.enable_grad():
+        Xg = X.double().detach().requires_grad_(True)
+        K, _, _ = _kprime(Xg, gspec, hband if gspec.kind == 2 else None)
+        (dX,) = torch.autograd.grad((0.5 * W.double().reshape(K.shape) * K).sum(), Xg)
+    return dX.to(X.dtype)

@@ -127,13 +127,58 @@ def test_batched_combine_slice_equals_per_layer(M, Ml, B, world):
         assert torch.equal(Wb[l], ops.combine_slice(A[l], Cs[l], gamma[l], B, s, True)), l
 
 
+@pytest.mark.parametrize('Ml,B,rows', [(8, 512, 64), (16, 256, 64), (32, 128, 64), (64, 128, 128)])
+def test_blocked_layouts_are_bit_equal_to_the_standard_ones(Ml, B, rows):
+    """The layouts of the one-all_to_all-per-exchange path (64 members in blocks of Ml rows, all layers in one buffer):
+    pairwise and combine on [G][L][Ml][n] == the same kernels on [L][64][n]; the all-layers Gram written as
+    [B/rows][L][M][rows][B] and dX read from it == the per-layer slice-major calls.  Bit for bit."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(Ml + B)
+    M, G, L, n = 64, 64 // Ml, 3, rows * B
+    assert ops.blocked_eligible(M, n, Ml)
+    Cstd = torch.randn(L, M, n, device=dev)
+    Cblk = Cstd.view(L, G, Ml, n).permute(1, 0, 2, 3).contiguous()
+    assert torch.equal(ops.pairwise_self_blocked(Cblk), ops.pairwise_self_batched(Cstd))
+    A = torch.randn(L, M, M, device=dev) / M
+    gamma = torch.randn(L, M, B, device=dev)
+    n_start = n * (1 if B * B >= 2 * n else 0)
+    Wstd = ops.combine_slice_batched(A, Cstd, gamma, B, n_start, True)
+    for l0, Lc in ((0, 1), (1, 2), (0, 3)):
+        Wb = ops.combine_slice_blocked(A[l0:l0 + Lc].contiguous(), Cblk, gamma[l0:l0 + Lc].contiguous(), l0, B, n_start, True)
+        assert Wb.shape == (G, Lc, Ml, n)
+        assert torch.equal(Wb.permute(1, 0, 2, 3).reshape(Lc, M, n), Wstd[l0:l0 + Lc]), (l0, Lc)
+    # Gram / dX with every layer in one buffer (a rank's Ml members)
+    # (8 members x 512 samples with deep layers: the launch splits them over K - slabs, then the placing reduction)
+    Ps = (4096, 2048, 256) if Ml == 8 else ((512, 256, 128) if B % 256 == 0 else (256, 128, 128))
+    Xs = [torch.randn(Ml, B, p, device=dev) * (1 + i) for i, p in enumerate(Ps)]
+    per = ops.centered_gram_multi(Xs, slice_rows=rows)
+    one, buf = ops.centered_gram_multi(Xs, slice_rows=rows, one_buffer=True)
+    assert buf.shape == (B // rows, L, Ml, rows, B)
+    for (C, cvec, xmax), (Cv, cv2, xm2) in zip(per, one):
+        assert torch.equal(C, Cv) and torch.equal(cvec, cv2) and torch.equal(xmax, xm2)
+    Wbuf = torch.randn(B // rows, L, Ml, rows, B, device=dev)
+    wmaxs = [Wbuf[:, k].abs().amax(dim=(0, 2, 3)) for k in range(L)]
+    xmaxs = [X.abs().amax(dim=(1, 2)) for X in Xs]
+    want = ops.gram_bwd_multi([Wbuf[:, k].contiguous() for k in range(L)], Xs, wmaxs, xmaxs, slice_rows=rows)
+    got = ops.gram_bwd_multi([Wbuf[:, k] for k in range(L)], Xs, wmaxs, xmaxs, slice_rows=rows, slice_members=L * Ml)
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+
+
 def _case(name):
     torch.manual_seed(17)
-    M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9)), 'm64b512': (64, 512, (2048, 256))}[name]
+    M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9)), 'm64b512': (64, 512, (2048, 256)),
+                'm12cos': (12, 40, (24, 9, 16)), 'm16rbf': (16, 64, (30, 40))}[name]
     feats = [torch.randn(M, B, p) * (1.0 + 0.5 * i) for i, p in enumerate(Ps)]
-    cfg = {'name': 'model_layers', 'reduction': 'mean',
-           'layer_kernel': {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031,
-                            'feature_kernel': {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}},
+    fk = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
+    lk = {'name': 'he', 'eps': 0.0025, 'arc_eps': 0.031}
+    if name == 'm12cos':        # the hypernetwork's kernel (configs/mnist/hyper/mlp-he.yml)
+        fk['kernel'] = 'cossim'
+    if name == 'm16rbf':        # the toy configuration's (configs/toy/fourclass/ens/he-rbf.yml)
+        fk.update(kernel='rbf', params={'param': 5.025})
+        lk = {'name': 'he', 'he_s': 5.0, 'eps': 0.000005, 'arc_eps': 0.00305}
+    cfg = {'name': 'model_layers', 'reduction': 'mean', 'layer_kernel': dict(lk, feature_kernel=fk),
            'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2, 0.7][:len(Ps)]}}
     return cfg, feats
 
@@ -158,7 +203,8 @@ def _worker(rank, world, port, name, out, mode):
 
 
 @pytest.mark.parametrize('name,world,mode', [('m64', 2, 'slice'), ('m64', 4, 'slice'), ('m12', 3, 'slice'),
-                                             ('m64', 2, 'gather'), ('m64b512', 8, 'slice')])   # the last: the bench's
+                                             ('m64', 2, 'gather'), ('m12cos', 3, 'slice'), ('m16rbf', 2, 'slice'),
+                                             ('m64b512', 8, 'slice')])   # the last: the bench's
 # member / sample counts at the driver's largest world size (8 members per rank, 32768-column slices, split-K Grams)
 def test_ranks_on_one_card_match_unsharded(name, world, mode, tmp_path):
     import torch.multiprocessing as mp

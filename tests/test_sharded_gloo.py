@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, cfgname, out, mode):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode,
-                      CPU_BACKEND_MULTI='1' if cfgname == 'he_sliced' else '0')
+                      CPU_BACKEND_MULTI='1' if cfgname in ('he_sliced', 'he_blocked') else '0',
+                      CPU_BACKEND_BLOCKED='1' if cfgname == 'he_blocked' else '0',
+                      HECKA_SHARD_EXCHANGE='p2p' if cfgname == 'he_p2p' else 'a2a')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import cpu_backend
     from hyper_amd.diversity.model_kernels import build_model_kernel
@@ -26,8 +28,22 @@ def _worker(rank, world, port, cfgname, out, mode):
     Ml = M // world
     xs = [f[rank * Ml:(rank + 1) * Ml].clone().requires_grad_(True) for f in feats]
     kern = ShardedModelLayersKernel(build_model_kernel(cfg), backend=cpu_backend)
+    from hyper_amd import parallel
+    n0 = parallel.COLLECTIVES
     loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
     loss.backward()
+    launched = parallel.COLLECTIVES - n0
+    if cfgname in ('he_p2p', 'he_blocked'):
+        # whatever the number of layers: forward one exchange + one all-gather, backward one exchange - two when the
+        # deepest layer's slices travel first (three and more layers)
+        assert launched == (4 if len(xs) >= 3 else 3), launched
+    elif mode == 'slice':       # per-layer all_to_all_single: L forward + one all-gather + L backward
+        assert launched == 2 * len(xs) + 1, launched
+    if cfgname == 'he_blocked':
+        assert cpu_backend.CALLS == {'gram_multi_one_buffer': 1, 'pairwise_blocked': 1, 'combine_blocked': 2,
+                                     'bwd_multi_sliced': 2}, cpu_backend.CALLS
+    if cfgname in ('he_cossim', 'he_rbf'):
+        assert cpu_backend.CALLS.get('transform_bwd') == len(xs), cpu_backend.CALLS
     if cfgname == 'he_sliced':
         # (three layers: the deepest one's dX as soon as its slices are in, the other two in one call behind it)
         assert cpu_backend.CALLS == {'gram_multi_sliced': 1, 'combine_batched': 1, 'bwd_multi_sliced': 2}, cpu_backend.CALLS
@@ -39,14 +55,22 @@ def _case(name):
     torch.manual_seed(21)
     B = 5 if name == 'he_uneven' else 12      # B*B = 25 does not split evenly: slices of 12/13 and 8/8/9 elements
     M = 6
-    if name == 'he_sliced':                   # slices of whole Gram rows (4 / 2 of 8): the slice-major layouts, no repacking
+    if name in ('he_sliced', 'he_blocked'):   # slices of whole Gram rows (4 / 2 of 8): the slice-major layouts, no repacking
         M, B = 8, 8
-    feats = [torch.randn(M, B, p, dtype=torch.float64) for p in ((9, 20, 14) if name == 'he_sliced' else (9, 20))]
+    feats = [torch.randn(M, B, p, dtype=torch.float64) for p in ((9, 20, 14) if name in ('he_sliced', 'he_blocked', 'he_rbf') else (9, 20))]
     lk = {'he': dict(name='he', eps=0.0025, arc_eps=0.031), 'he_uneven': dict(name='he', eps=0.0025, arc_eps=0.031),
           'he_sliced': dict(name='he', eps=0.0025, arc_eps=0.031),
+          'he_p2p': dict(name='he', eps=0.0025, arc_eps=0.031),
+          'he_blocked': dict(name='he', eps=0.0025, arc_eps=0.031),
+          'he_cossim': dict(name='he', eps=0.0025, arc_eps=0.031),          # configs/mnist/hyper/mlp-he.yml's kernel
+          'he_rbf': dict(name='he', he_s=5.0, eps=0.000005, arc_eps=0.00305),   # configs/toy/fourclass/ens/he-rbf.yml's
           'he_exp_dr': dict(name='he', eps=0.001, arc_eps=0.001, use_exp=True, detach_right=True),
           'cka': dict(name='cka', eps=1e-6)}[name]
     lk['feature_kernel'] = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
+    if name == 'he_cossim':
+        lk['feature_kernel']['kernel'] = 'cossim'
+    if name == 'he_rbf':
+        lk['feature_kernel'].update(kernel='rbf', params={'param': 5.025})
     cfg = {'name': 'model_layers', 'layer_kernel': lk, 'reduction': 'mean',
            'layer_weighting': {'name': 'list', 'weights': [0.3, 1.2, 0.7][:len(feats)]}}
     return cfg, feats
@@ -78,6 +102,28 @@ def test_slice_major_layouts_and_batched_stages_match_oracle(world, tmp_path):
     """The branch of hyper_amd.parallel the GPU path takes when a slice is whole Gram rows: Grams produced directly in
     the all-to-all's send order, W consumed as it arrives, one combine / bounds / dX call for all layers."""
     test_sharded_matches_single_process_oracle('he_sliced', world, 'slice', tmp_path)
+
+
+@pytest.mark.parametrize('name', ['he_cossim', 'he_rbf'])
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_cossim_and_rbf_layers_match_oracle(name, world, tmp_path):
+    """cossim / rbf Grams (the hypernetwork and toy configurations) through the sliced scheme: the row-wise transform and
+    its backward stay with the member's owner, its row means travel in cvec's place."""
+    test_sharded_matches_single_process_oracle(name, world, 'slice', tmp_path)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_batched_send_receive_exchange_matches(world, tmp_path):
+    """HECKA_SHARD_EXCHANGE=p2p: every layer's segments of an exchange in one batched send / receive group instead of
+    one all_to_all_single per layer."""
+    test_sharded_matches_single_process_oracle('he_p2p', world, 'slice', tmp_path)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_blocked_layouts_one_all_to_all_per_exchange(world, tmp_path):
+    """The bench's branch: all layers in one buffer, ONE all_to_all_single per exchange (4 collectives per evaluation),
+    the small stages on the received layout [source rank][layer][members][n]."""
+    test_sharded_matches_single_process_oracle('he_blocked', world, 'slice', tmp_path)
 
 
 def test_slice_bounds():
