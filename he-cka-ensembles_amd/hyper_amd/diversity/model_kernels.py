@@ -15,12 +15,11 @@ are outside the hot path and are not built."""
 import copy
 from collections import OrderedDict
 
-import os
-
 import torch
 import torch.nn as nn
 
 from .. import ops
+from ..config import knobs
 from ..util.collections import flatten_keys
 from . import cos_from_inner, energy_from_cos, hyperspherical_energy, pairwise_cossim
 from .kernels import KERN_PARAMS, MAPS, batched_gram, center_gram
@@ -325,22 +324,6 @@ class ModelLayersKernel(BaseModelKernel):
             return model_grams.sum()
         return model_grams
 
-    # Layers are independent until the final weighted sum.  HECKA_LAYER_STREAMS = n > 1 enqueues each layer's kernel
-    # chain on its own HIP stream (round-robin over n; autograd replays every node on its forward stream).  That paid
-    # (+8 %) while every layer launched its own Gram GEMM - a second layer filled the GPU's ragged second scheduling
-    # round - and stopped paying once all layers' Grams became ONE launch (ops.centered_gram_multi): measured
-    # 225.9 evals/s in order on one stream vs 223.6 on four.  Default: everything in order on the current stream.
-    num_streams = int(os.environ.get('HECKA_LAYER_STREAMS', '1'))
-    # (stream priorities were tried: with more streams than hardware queues a high-priority stream starved the rest
-    # - 0.6 evals/s - so all layer streams keep the default priority)
-    _streams = {}
-
-    def _side_streams(self, device, n):
-        key = (device.index, n)
-        if key not in ModelLayersKernel._streams:
-            ModelLayersKernel._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-        return ModelLayersKernel._streams[key]
-
     def _layer_value(self, kern, params, feat, pred, ltrack, pre=None):
         if self.reduction in ('mean', 'sum') and isinstance(kern, _PairwiseHead):
             return kern.reduced(feat, ltrack, self.reduction, pre)   # reduced inside the head kernel
@@ -349,7 +332,7 @@ class ModelLayersKernel(BaseModelKernel):
     def _shared_grams(self, kerns, flist):
         """Centred Grams of ALL layers from one launch (None when some layer is not on the fused linear path, or the
         shapes are not interior): a single layer's Gram grid leaves most of the GPU's second scheduling round empty."""
-        if os.environ.get('HECKA_MULTI_GRAM', '1') == '0' or self.reduction not in ('mean', 'sum'):
+        if not knobs.multi_gram or self.reduction not in ('mean', 'sum'):
             return None
         if not all(isinstance(k, _PairwiseHead) and k.shares_gram_launch() for k in kerns):
             return None
@@ -366,9 +349,9 @@ class ModelLayersKernel(BaseModelKernel):
         path with a host-float weight and an interior shape (a net's tiny last layer - 10 logits - must not keep its
         64-channel feature maps from the shared launch)."""
         none = (None, frozenset())
-        if os.environ.get('HECKA_FUSED_LAYERS', '1') == '0' or os.environ.get('HECKA_MULTI_GRAM', '1') == '0':
+        if not (knobs.fused_layers and knobs.multi_gram):
             return none
-        if self.reduction not in ('mean', 'sum') or self.num_streams > 1:
+        if self.reduction not in ('mean', 'sum'):
             return none
         total = len(flist)
         weights = [self.layer_weighting.get_weight(index, total) for index in range(total)]
@@ -393,7 +376,7 @@ class ModelLayersKernel(BaseModelKernel):
                 if X.is_cuda and X.dtype == torch.float32 and X.ndim == 3 and X.numel() > 0:
                     loose.setdefault((X.shape[0], X.shape[1], kerns[i].feature_kernel.detach_diag), []).append(i)
             best = max(loose.values(), key=len) if loose else []
-            if os.environ.get('HECKA_FUSED_RAGGED', '1') == '0':
+            if not knobs.fused_ragged:
                 return none
             if len(best) < 2:
                 return self._fused_transformed(kerns, flist, layer_track, weights)
@@ -470,38 +453,13 @@ class ModelLayersKernel(BaseModelKernel):
                 out = out + self.layer_weighting.get_weight(index, total) * value
             track['layer_track'] = layer_track
             return out
-        nstream = min(self.num_streams, total) if flist[0].is_cuda else 0
+        # layers one after another on the current stream (per-layer streams were measured and lost once all layers' Grams
+        # became one launch: DESIGN.md 4)
         pre = self._shared_grams(kerns, flist) if flist[0].is_cuda else None
         values = []
-        if nstream > 1:
-            main = torch.cuda.current_stream(flist[0].device)
-            streams = self._side_streams(flist[0].device, nstream)
-            for st in streams:
-                st.wait_stream(main)
-            # biggest layers first, each on the next stream: their long GEMM chains start early
-            order = sorted(range(total), key=lambda i: -flist[i][0].numel())
-            slot = {layer: k % nstream for k, layer in enumerate(order)}
-            values = [None] * total
-            for index in order:
-                feat = flist[index]
-                st = streams[slot[index]]
-                with torch.cuda.stream(st):
-                    if pre is not None:
-                        for t in pre[index]:
-                            t.record_stream(st)
-                    v = self._layer_value(kerns[index], params, feat, pred, layer_track[index],
-                                          pre[index] if pre is not None else None)
-                    v.record_stream(main)
-                    g = layer_track[index].get('gram')
-                    if g is not None:
-                        g.record_stream(main)
-                values[index] = v
-            for st in streams:
-                main.wait_stream(st)
-        else:
-            for index, feat in enumerate(flist):
-                values.append(self._layer_value(kerns[index], params, feat, pred, layer_track[index],
-                                                pre[index] if pre is not None else None))
+        for index, feat in enumerate(flist):
+            values.append(self._layer_value(kerns[index], params, feat, pred, layer_track[index],
+                                            pre[index] if pre is not None else None))
         weights = [self.layer_weighting.get_weight(index, total) for index in range(total)]
         if all(v.ndim == 0 for v in values) and not any(isinstance(w, torch.Tensor) for w in weights):
             # host-float weights and scalar layer values: one stack + one dot instead of 2 L tiny kernels (and 2 L more

@@ -32,7 +32,6 @@ class GraphedTrainStep:
         self.kwargs = dict(sample_params=True, ret_params=True, feature_split=True, ood_N=0)
         self.kwargs.update(forward_kwargs or {})
         self.trainer = trainer if trainer is not None else types.SimpleNamespace(training=True)
-        from .. import ops
         cur = torch.cuda.current_stream(x.device)
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(cur)
@@ -41,12 +40,10 @@ class GraphedTrainStep:
                 self._body()
         cur.wait_stream(side)
         torch.cuda.synchronize(x.device)
-        ops._GemmChain.last.clear()                # events recorded outside the capture must not be waited on inside it
         optimizer.zero_grad(set_to_none=True)      # gradients are allocated inside the capture, from the graph's pool
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body(captured=True)
-        ops._GemmChain.last.clear()
 
     def _body(self, captured=False):
         if not captured:      # inside the capture .grad is None at the start: backward ASSIGNS into the graph's buffers

@@ -6,7 +6,6 @@ epilogue and the bias carried as an extra weight column against a row of ones, a
 input gradient.  The gathered patches are kept for the weight gradient (HECKA_CONV_KEEP_COLS_GB per layer, default 8)
 and re-gathered in backward beyond that."""
 import math
-import os
 
 import numpy as np
 import torch
@@ -15,6 +14,7 @@ import torch.nn.init as init
 from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 
 from .. import _lib, ops
+from ..config import knobs
 from ..net import activation
 from .linear import _absmax_rows, _bgemm, _bgemm_x3, _x3_eligible
 from .norm import cached_absmax
@@ -71,7 +71,7 @@ def _conv_tab(Cin, H, W, kh, kw, ph, pw, device, rows=None):
 
 def _conv_x3_ok(geom, M, rows, K, N, Cin, H, W):
     kh, kw, sh, sw, ph, pw, dh, dw = geom
-    return (os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0' and os.environ.get('HECKA_CONV_X3', '1') != '0'
+    return (knobs.conv_implicit and knobs.conv_x3
             and sh == 1 and sw == 1 and dh == 1 and dw == 1 and 2 * ph == kh - 1 and 2 * pw == kw - 1
             and ops.get_gemm_mode() == 0 and bool(_lib.lib().hecka_conv_x3_eligible(M, rows, K, N, Cin, H, W)))
 
@@ -88,7 +88,7 @@ def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB
 def _direct_ok(geom, C, O):
     """Few-channel direct convolution (hecka_conv_direct_f32): unit stride, no dilation, equal zero padding on both axes."""
     kh, kw, sh, sw, ph, pw, dh, dw = geom
-    return (os.environ.get('HECKA_CONV_DIRECT', '1') != '0' and sh == 1 and sw == 1 and dh == 1 and dw == 1 and ph == pw
+    return (knobs.conv_direct and sh == 1 and sw == 1 and dh == 1 and dw == 1 and ph == pw
             and ph <= kh - 1 and bool(_lib.lib().hecka_conv_direct_eligible(C, O, kh, kw)))
 
 
@@ -170,7 +170,7 @@ class BatchedConv2d(torch.autograd.Function):
             y = _bgemm(Wf, cols, M, O, Q, R, O * R, 0 if shared else R * Q, True, scale)      # [M,O,Q]
         # the gathered patches are kept for the weight gradient while they are small next to 288 GB of HBM (23 GB for
         # all of ResNet18 at M=10, N=128); larger ones are re-gathered in backward
-        keep = cols.numel() * 4 <= int(float(os.environ.get('HECKA_CONV_KEEP_COLS_GB', '8')) * 2 ** 30)
+        keep = cols.numel() * 4 <= int(knobs.conv_keep_cols_gb * 2 ** 30)
         ctx.save_for_backward(x5, W, cols if keep else None, xmax, wmax)
         ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
         return y.view(M, O, N, Ho, Wo).transpose(1, 2)
@@ -220,8 +220,8 @@ class BatchedConv2d(torch.autograd.Function):
         Rp = (K + 127) // 128 * 128
         L = _lib.lib()
         if (ctx.needs_input_grad[1] and not has_bias and dymax is not None and geom[2:] == (1, 1, geom[4], geom[5], 1, 1)
-                and 2 * geom[4] == kh - 1 and 2 * geom[5] == kw - 1 and os.environ.get('HECKA_CONV_IMPLICIT', '1') != '0'
-                and os.environ.get('HECKA_CONV_X3', '1') != '0' and ops.get_gemm_mode() == 0
+                and 2 * geom[4] == kh - 1 and 2 * geom[5] == kw - 1 and knobs.conv_implicit
+                and knobs.conv_x3 and ops.get_gemm_mode() == 0
                 and L.hecka_conv_wgrad_x3_eligible(M, O, Rp, N, C, H, Wd)):
             # weight gradient with both operands implicit: dy as it lies (NCHW), patches gathered in the kernel
             dWp = torch.empty((M, O, Rp), device=dy.device, dtype=torch.float32)

@@ -3,13 +3,13 @@
 fp32 MFMA (libhecka hecka_bgemm_f32) with the parameter scaling and the bias add folded into the epilogue."""
 import math
 
-import os
 
 import torch
 import torch.nn.functional as F
 import torch.nn.init as init
 
 from .. import _lib, ops
+from ..config import knobs
 from ..net import activation
 from .module import ParametersGroup, register_gen_module
 
@@ -40,7 +40,7 @@ def _absmax_rows(V, rows):
 
 
 def _x3_eligible(batch, rows, cols, K):
-    return (os.environ.get('HECKA_CONV_X3', '1') != '0' and ops.get_gemm_mode() == 0      # fp16-split only in HECKA_GEMM_AUTO
+    return (knobs.conv_x3 and ops.get_gemm_mode() == 0      # fp16-split only in HECKA_GEMM_AUTO
             and bool(_lib.lib().hecka_bgemm_x3_eligible(batch, rows, cols, K)))
 
 

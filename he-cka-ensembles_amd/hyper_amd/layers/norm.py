@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..config import knobs
 from .module import GenModule, ParametersGroup
 
 
@@ -148,8 +149,7 @@ class BatchedBatchNormAct(torch.autograd.Function):
 
 def fused_act_eligible(x):
     """The fused norm (+ residual) + relu launch takes fp32 GPU tensors with a multiple of four positions per channel."""
-    import os
-    return (os.environ.get('HECKA_BN_FUSE', '1') != '0' and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
+    return (knobs.bn_fuse and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
             and int(x[0, 0, 0].numel()) % 4 == 0)
 
 

@@ -7,12 +7,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import os
 
 from .. import _lib
+from ..config import knobs
 
 # A/B handle: HECKA_SAMPLER_TORCH=linear,groupnorm,matvec sends the named pieces back to the torch expressions
-_TORCH = set(filter(None, os.environ.get('HECKA_SAMPLER_TORCH', '').split(',')))
 
 
 def _hip(*ts):
@@ -25,7 +24,7 @@ def _st(t):
 
 def linear(x, weight, bias=None):
     """F.linear(x, weight, bias) for a weight shared by all members: one grouped-GEMM launch (forward, dgrad, wgrad)."""
-    if not _hip(x, weight, bias) or 'linear' in _TORCH:
+    if not _hip(x, weight, bias) or 'linear' in knobs.sampler_torch:
         return F.linear(x, weight, bias)
     from ..layers.linear import BatchedLinear
     lead = x.shape[:-1]
@@ -63,14 +62,14 @@ class _MatVec(torch.autograd.Function):
 
 def matvec(W, v):
     """torch.mv(W, v)."""
-    if not _hip(W, v) or 'matvec' in _TORCH:
+    if not _hip(W, v) or 'matvec' in knobs.sampler_torch:
         return torch.mv(W, v)
     return _MatVec.apply(W, v)
 
 
 def matvec_t(W, u):
     """torch.mv(W.t(), u) without autograd (the power iteration runs under no_grad)."""
-    if not _hip(W, u) or not W.is_contiguous() or 'matvec' in _TORCH:
+    if not _hip(W, u) or not W.is_contiguous() or 'matvec' in knobs.sampler_torch:
         return torch.mv(W.t(), u)
     L = _lib.lib()
     H, Wd = W.shape
@@ -116,7 +115,7 @@ class _GroupNormAct(torch.autograd.Function):
 
 def group_norm(x, groups, weight, bias, eps, gelu=False):
     """F.group_norm on [N, C] rows, optionally followed by F.gelu (erf form), in one kernel each way."""
-    if x.ndim != 2 or not _hip(x, weight, bias) or x.shape[0] > 65535 or 'groupnorm' in _TORCH:
+    if x.ndim != 2 or not _hip(x, weight, bias) or x.shape[0] > 65535 or 'groupnorm' in knobs.sampler_torch:
         y = F.group_norm(x, groups, weight, bias, eps)
         return F.gelu(y) if gelu else y
     return _GroupNormAct.apply(x, weight, bias, groups, eps, 1 if gelu else 0)

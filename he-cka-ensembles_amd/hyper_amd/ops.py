@@ -9,6 +9,7 @@ import threading
 import torch
 
 from . import _lib
+from .config import knobs
 
 
 # bench.py sets this to {'gram_bwd': []} to collect (start_event, end_event, flops) around the dominant
@@ -117,7 +118,7 @@ def native16_eligible(Xs):
     """bf16 / fp16 features that the x16 entry points read as they lie in HBM (no up-cast pass; dX comes back in the
     feature type): GPU tensors of ONE 16-bit type with the same members and samples, B % 128 == 0, every P % 128 == 0,
     split-precision GEMM mode.  HECKA_NATIVE16=0 forces the up-cast path."""
-    if not Xs or os.environ.get('HECKA_NATIVE16', '1') == '0':
+    if not Xs or not knobs.native16:
         return False
     dt, M, B = Xs[0].dtype, Xs[0].shape[0], Xs[0].shape[1] if Xs[0].ndim == 3 else 0
     if dt not in (torch.bfloat16, torch.float16) or B % 128 or B == 0:
@@ -149,36 +150,6 @@ def _check_features(X, allow16=False):
         raise RuntimeError('expected features of shape [members, samples, features]')
 
 
-class _GemmChain:
-    """The two big GEMMs (centred Gram, dX) each fill the whole GPU, so running two of them side by side from
-    different layer streams only stretches both.  Every big-GEMM launch therefore waits for the previous one (an event
-    chain across the layer streams, enqueue order); the small HBM-bound kernels of other layers still overlap them.
-    HECKA_GEMM_CHAIN=0 disables the chain."""
-    enabled = os.environ.get('HECKA_GEMM_CHAIN', '1') != '0'
-    last = {}
-
-    @classmethod
-    def enter(cls, device):
-        if not cls.enabled or torch.cuda.is_current_stream_capturing():
-            # (under graph capture the chain is skipped: an eager event must not be waited on inside a capture, and an
-            # event recorded inside one must not leak into eager code; capture orders the launches by itself)
-            cls.last.pop(device.index, None)
-            return None
-        cur = torch.cuda.current_stream(device)
-        prev = cls.last.get(device.index)
-        if prev is not None and prev[1] != cur.cuda_stream:
-            cur.wait_event(prev[0])
-        return cur
-
-    @classmethod
-    def leave(cls, device, cur):
-        if cur is None:
-            return
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        cls.last[device.index] = (ev, cur.cuda_stream)
-
-
 def centered_gram(X, return_xmax=False, out=None):
     """X [M,B,P] -> (C [M,B,B] = K - rowmean(K), cvec [M,B]) with K = X X^T; no autograd.
     `return_xmax` adds xmax [M] = max |X[m]| (a by-product of the column-mean pass) for gram_backward: with it the
@@ -198,9 +169,7 @@ def centered_gram(X, return_xmax=False, out=None):
     cvec = torch.empty((M, B), device=X.device, dtype=torch.float32)
     st = _stream()
     _lib.check(L.hecka_colmean_f32(_p(X), M, B, P, _p(sbar), _p(xmax), st), 'colmean')
-    gate = _GemmChain.enter(X.device)
     _lib.check(L.hecka_gram_center_f32(_p(X), _p(sbar), _p(xmax), M, B, P, _p(C), _p(cvec), get_gemm_mode(), st), 'gram_center')
-    _GemmChain.leave(X.device, gate)
     return (C, cvec, xmax) if return_xmax else (C, cvec)
 
 
@@ -224,7 +193,7 @@ def multi_gram_eligible(Xs):
         return get_gemm_mode() != 1
     # ragged: the masked split-precision tile.  (A single ragged layer takes it only when its grid fills the GPU - the
     # library's per-layer rule; two or more layers in ONE launch pay even on small grids: MNIST 5 x 300, +4 % steps/s.)
-    return B % 4 == 0 and get_gemm_mode() == 0 and os.environ.get('HECKA_RAGGED_X3') != '0'
+    return B % 4 == 0 and get_gemm_mode() == 0 and knobs.ragged_x3 != '0'
 
 
 def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
@@ -257,7 +226,7 @@ def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])   # noqa: E731
     xmax_all = torch.empty((n, M), device=dev, dtype=torch.float32)
     sbars = [torch.empty((M, X.shape[2]), device=dev, dtype=torch.float32) for X in Xs]
-    one_colmean = dt == 0 and all(X.shape[2] % 4 == 0 for X in Xs) and os.environ.get('HECKA_COLMEAN_MULTI', '1') != '0'
+    one_colmean = dt == 0 and all(X.shape[2] % 4 == 0 for X in Xs) and knobs.colmean_multi
     if one_colmean:      # every layer's column means (and maxima) in one launch, deepest layer first
         _lib.check(L.hecka_colmean_multi_f32(n, ptrs([Xs[i] for i in order]), M, B, (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]),
                                              ptrs([sbars[i] for i in order]), _p(xmax_all), st), 'colmean_multi')
@@ -374,7 +343,6 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
             and gram_bwd_multi_eligible([W], [X], [wmax], [xmax])):
         return gram_bwd_multi([W], [X], [wmax], [xmax], gate)[0]      # one layer on the 256 x 256 eight-wave tile
     dX = torch.empty_like(X)
-    chain = _GemmChain.enter(X.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -385,16 +353,15 @@ def gram_bwd_w(W, X, wmax=None, xmax=None, gate=None):
         e1.record()
         PROFILE['gram_bwd'].append((e0, e1, 2.0 * Ma * B * B * P))
         global LAST_BWD_KERNEL
-        tile = 256 if (B % 256 == 0 and B <= 1024 and os.environ.get('HECKA_BWD_TILE', '256') == '256') else 128
+        tile = 256 if (B % 256 == 0 and B <= 1024) else 128
         LAST_BWD_KERNEL = 'gram_bwd_x6_kernel<1, false, 0, %d>' % tile
-    _GemmChain.leave(X.device, chain)
     return dX
 
 
 def gram_bwd_multi_eligible(Ws, Xs, wmaxs, xmaxs, slice_rows=0):
     """Every layer's dX = W X in ONE launch (hecka_gram_bwd_multi_f32): fp32 features, f16x3 mode with all maxima."""
     import ctypes
-    if not 1 <= len(Xs) <= 16 or get_gemm_mode() != 0 or os.environ.get('HECKA_BWD_MULTI', '1') == '0':
+    if not 1 <= len(Xs) <= 16 or get_gemm_mode() != 0 or not knobs.bwd_multi:
         return False
     if any(w is None for w in wmaxs) or any(x is None for x in xmaxs):
         return False
@@ -416,7 +383,6 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0, slice_members=
     dXs = [torch.empty_like(X) for X in Xs]
     ptrs = lambda ts: (ctypes.c_void_p * n)(*[ts[i].data_ptr() for i in order])   # noqa: E731
     Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
-    chain = _GemmChain.enter(Xs[0].device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -429,12 +395,11 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0, slice_members=
         global LAST_BWD_KERNEL
         interior = B % 128 == 0 and all(X.shape[2] % 128 == 0 for X in Xs)
         tm = 256 if interior and B % 256 == 0 else 128
-        wide = tm == 256 and all(X.shape[2] % 256 == 0 for X in Xs) and os.environ.get('HECKA_BWD_TN', '256') == '256'
-        k32 = wide and os.environ.get('HECKA_K32', '1') != '0'      # the 16x16x32 tile (gemm_f16x3_k32.hpp)
+        wide = tm == 256 and all(X.shape[2] % 256 == 0 for X in Xs) and knobs.bwd_tn == '256'
+        k32 = wide and knobs.k32      # the 16x16x32 tile (gemm_f16x3_k32.hpp)
         LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s, %d, %s>' % (
             tm, 'false' if interior else 'true', 'true' if slice_rows else 'false', 256 if wide else 128,
             'true' if k32 else 'false')
-    _GemmChain.leave(Xs[0].device, chain)
     return dXs
 
 

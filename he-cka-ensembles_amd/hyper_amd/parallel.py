@@ -26,10 +26,10 @@ gather - the first scheme: all_gather the local Grams to C_all [M, B, B] on ever
 tests inject an oracle-backed backend to check the sharding logic without a GPU; the product path never
 does.  With the gloo backend and GPU tensors (a rehearsal of several ranks on one card) the collectives are
 staged through the host."""
-import os
-
 import torch
 import torch.distributed as dist
+
+from .config import knobs
 
 
 EXCHANGED_BYTES = 0      # bytes this rank has SENT through the collectives below (bench.py reports it per evaluation)
@@ -81,10 +81,7 @@ def exchange_mode():
     apply.  HECKA_SHARD_EXCHANGE = a2a (default): one all_to_all_single per layer.  p2p: every layer's segments of an
     exchange in ONE batched send / receive group (torch.distributed.batch_isend_irecv: on RCCL one ncclGroup, i.e. one
     device launch whatever the number of layers, but 2 L (G - 1) Python-level operations on the host)."""
-    mode = os.environ.get('HECKA_SHARD_EXCHANGE', 'a2a')
-    if mode not in ('p2p', 'a2a'):
-        raise ValueError("HECKA_SHARD_EXCHANGE must be 'p2p' or 'a2a'")
-    return mode
+    return knobs.shard_exchange
 
 
 def _exchange(sends, recvs, send_splits, recv_splits, group):
@@ -221,9 +218,9 @@ class _SlicedLayers(torch.autograd.Function):
         rows = n_r // B if (even and n_r % B == 0) else 0
         sliced = (world > 1 and multi and rows > 0 and rows & (rows - 1) == 0 and
                   feats[0].dtype in getattr(backend, 'SLICED_DTYPES', (torch.float32,)) and
-                  hasattr(backend, 'gram_bwd_multi') and os.environ.get('HECKA_SHARD_REPACK', '0') != '1')
+                  hasattr(backend, 'gram_bwd_multi'))
         blocked = (sliced and hasattr(backend, 'blocked_eligible') and backend.blocked_eligible(M, n_r, Ml) and
-                   os.environ.get('HECKA_SHARD_BLOCKED', '1') != '0')
+                   knobs.shard_blocked)
         Cbuf = None
         if blocked:
             pre, Cbuf = backend.centered_gram_multi(feats, slice_rows=rows, one_buffer=True)      # [G, L, Ml, rows, B]
@@ -341,7 +338,7 @@ class _SlicedLayers(torch.autograd.Function):
                          for li in range(L)]
         # layers are in depth order: the deepest layer's slices travel first, and its dX GEMM (half the flops at the
         # bench's widths) runs while the other layers' slices are still on the links
-        split = world > 1 and L >= 3 and os.environ.get('HECKA_SHARD_BWD_SPLIT', '1') != '0'
+        split = world > 1 and L >= 3 and knobs.shard_bwd_split
         parts = [[0], list(range(1, L))] if split else [list(range(L))]
         gate = (ctx.gate,) if ctx.gate is not None else ()
         grads = [None] * L
@@ -486,9 +483,7 @@ class _GatheredLayers(torch.autograd.Function):
 
 
 def shard_mode(backend):
-    mode = os.environ.get('HECKA_SHARD_MODE', 'slice')
-    if mode not in ('slice', 'gather'):
-        raise ValueError("HECKA_SHARD_MODE must be 'slice' or 'gather'")
+    mode = knobs.shard_mode
     if mode == 'slice' and not all(hasattr(backend, f) for f in ('coef_gamma', 'combine_slice', 'gram_bwd_w')):
         return 'gather'
     return mode
@@ -569,7 +564,6 @@ def shard_method(method, group=None, backend=None):
     weights - so the only exchange is the Gram column slices inside the kernel.  Unlike the reference's DDP (per-rank
     sub-batch Grams) the loss is the single-GPU loss.  Member-coupled OOD losses (`mean_softmax_entropy`
     averages the members' softmax) are refused."""
-    import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if getattr(method, 'ood_loss', None) is not None:
         raise NotImplementedError('shard_method: the OOD prediction loss averages over all members; not sharded')

@@ -15,6 +15,35 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _hecka_knobs(monkeypatch):
+    """hyper_amd and libhecka read their HECKA_* knobs once (hyper_amd/config.py, hecka_config_reload): a test that changes
+    one through `monkeypatch.setenv / delenv` gets the re-read here, and the defaults come back when the test ends."""
+    touched = []
+
+    def reload():
+        import hyper_amd.config
+        hyper_amd.config.reload()
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        orig_set(name, value, *a, **k)
+        if name.startswith('HECKA_'):
+            touched.append(name)
+            reload()
+
+    def delenv(name, *a, **k):
+        orig_del(name, *a, **k)
+        if name.startswith('HECKA_'):
+            touched.append(name)
+            reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    if touched:
+        monkeypatch.undo()
+        reload()
+
+
 def golden_cases(tag):
     """Model-kernel fixtures (the train-step fixtures `toy_*` / `lenet_*` / `resnet_*` / `hyper_*` and the layer fixtures `conv_*` have
     their own tests)."""

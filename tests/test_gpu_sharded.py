@@ -168,7 +168,9 @@ def test_blocked_layouts_are_bit_equal_to_the_standard_ones(Ml, B, rows):
 
 def _case(name):
     torch.manual_seed(17)
+    name = name.split(':')[0]
     M, B, Ps = {'m64': (64, 128, (256, 64, 48)), 'm12': (12, 40, (24, 9)), 'm64b512': (64, 512, (2048, 256)),
+                'm64b256': (64, 256, (512, 256, 256)),
                 'm12cos': (12, 40, (24, 9, 16)), 'm16rbf': (16, 64, (30, 40))}[name]
     feats = [torch.randn(M, B, p) * (1.0 + 0.5 * i) for i, p in enumerate(Ps)]
     fk = {'name': 'feature', 'detach_diag': True, 'kernel': 'linear'}
@@ -186,24 +188,33 @@ def _case(name):
 def _worker(rank, world, port, name, out, mode):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HECKA_SHARD_MODE=mode)
+    variant = name.split(':')[1] if ':' in name else ''
+    if variant:     # a knob's non-default value (read once, at import)
+        os.environ[{'noblocked': 'HECKA_SHARD_BLOCKED', 'nosplit': 'HECKA_SHARD_BWD_SPLIT'}[variant]] = '0'
     import torch.distributed as dist
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from hyper_amd.diversity.model_kernels import build_model_kernel
+    from hyper_amd import parallel
     from hyper_amd.parallel import ShardedModelLayersKernel
     dev = torch.device('cuda:0')
     cfg, feats = _case(name)
     Ml = feats[0].shape[0] // world
     xs = [f[rank * Ml:(rank + 1) * Ml].to(dev).requires_grad_(True) for f in feats]
     kern = ShardedModelLayersKernel(build_model_kernel(cfg).to(dev))
+    n0 = parallel.COLLECTIVES
     loss = kern(None, OrderedDict((str(i), x) for i, x in enumerate(xs)), None, OrderedDict())
     loss.backward()
     torch.cuda.synchronize()
+    if name.startswith('m64b256'):   # three layers: 4 collectives blocked (3 without the split), 2 L + 1 per layer otherwise
+        assert parallel.COLLECTIVES - n0 == {'': 4, 'nosplit': 3, 'noblocked': 7}[variant], parallel.COLLECTIVES - n0
     torch.save({'loss': loss.detach().cpu(), 'grads': [x.grad.cpu() for x in xs]}, '%s.%d' % (out, rank))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('name,world,mode', [('m64', 2, 'slice'), ('m64', 4, 'slice'), ('m12', 3, 'slice'),
                                              ('m64', 2, 'gather'), ('m12cos', 3, 'slice'), ('m16rbf', 2, 'slice'),
+                                             ('m64b256', 4, 'slice'), ('m64b256:noblocked', 4, 'slice'),
+                                             ('m64b256:nosplit', 4, 'slice'),
                                              ('m64b512', 8, 'slice')])   # the last: the bench's
 # member / sample counts at the driver's largest world size (8 members per rank, 32768-column slices, split-K Grams)
 def test_ranks_on_one_card_match_unsharded(name, world, mode, tmp_path):
