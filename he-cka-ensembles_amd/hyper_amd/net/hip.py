@@ -105,12 +105,18 @@ class _GroupNormAct(torch.autograd.Function):
         N, C = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if w is not None and ctx.needs_input_grad[1] else None
-        db = torch.empty_like(b) if b is not None and dw is not None and ctx.needs_input_grad[2] else None
+        # the affine-gradient kernel runs when dweight is given and fills dbias beside it: a frozen weight with a trainable
+        # bias (nn.GroupNorm gives that bias its gradient) gets a scratch dweight that is dropped
+        want_w = w is not None and ctx.needs_input_grad[1]
+        want_b = b is not None and ctx.needs_input_grad[2]
+        dw = torch.empty_like(w) if w is not None and (want_w or want_b) else None
+        db = torch.empty_like(b) if want_b and dw is not None else None
+        if want_b and dw is None:      # a bias without a weight cannot come out of the fused forward; be loud if it ever does
+            raise RuntimeError('group_norm: bias gradient requested without an affine weight')
         p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(_lib.lib().hecka_groupnorm_bwd_f32(dy.data_ptr(), x.data_ptr(), N, C, groups, p(w), p(b), mean.data_ptr(),
                                                      rstd.data_ptr(), act, p(dx), p(dw), p(db), _st(x)), 'groupnorm_bwd')
-        return dx, dw, db, None, None, None
+        return dx, (dw if want_w else None), db, None, None, None
 
 
 def group_norm(x, groups, weight, bias, eps, gelu=False):

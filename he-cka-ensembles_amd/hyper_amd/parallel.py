@@ -554,25 +554,130 @@ class _ScaledLoss(torch.nn.Module):
         return self.factor * self.loss(*args, **kwargs)
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over ranks of a quantity every rank then uses in the SAME global loss term: the gradient of that term with
+    respect to this rank's contribution is the upstream gradient itself (each rank differentiates its own copy of the
+    global term, and only through its own members)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        out = t.detach().clone()
+        _all_reduce(out, group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class ShardedMeanSoftmaxEntropy(torch.nn.Module):
+    """`mean_softmax_entropy` (hyper/diversity/losses.py:77: negative entropy of the MEMBER-AVERAGED softmax) when the
+    members are sharded: the local softmax sums [samples, classes] are added over the ranks (one tiny all-reduce), so the
+    value is the unsharded loss exactly and every rank's backward reaches its own members only."""
+
+    def __init__(self, group=None):
+        super().__init__()
+        self.group = group
+
+    def forward(self, model_bs, x, pred, gt):
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        psum = torch.nn.functional.softmax(pred, dim=-1).sum(0)
+        if world > 1:
+            psum = _AllReduceSum.apply(psum, self.group)
+        p = psum / (pred.shape[0] * world)
+        return -(-(p * torch.log(p + 1e-8)).sum(-1)).mean()
+
+
+class _ShardedInlierOutlierEntropy(torch.nn.Module):
+    """`inlier_outlier_entropy` (losses.py:94-113) under member sharding: cross-entropy of the local members / G + weight *
+    the exact member-averaged entropy term."""
+
+    def __init__(self, loss, world, group):
+        super().__init__()
+        self.loss, self.world, self.ood_entropy = loss, world, ShardedMeanSoftmaxEntropy(group)
+
+    def forward(self, model_bs, x, forward_data, gt):
+        return (self.loss.ce(model_bs, x, forward_data['pred_ind'], gt) / self.world
+                + self.loss.weight * self.ood_entropy(model_bs, x, forward_data['pred_ood'], None))
+
+
 def shard_method(method, group=None, backend=None):
-    """Member-sharded TRAINING (last sentence): every rank builds the ensemble with ITS members only
-    (`ensemble_size` = `num` = M / G, all on the full batch) and calls `shard_method` once on its `repulsive_kernel` /
-    `mle` method.  After that rank r's loss is  beta * CE(own members) / G + gamma * rep(ALL members)  and its backward
-    leaves on the local parameters exactly the gradients the unsharded step gives those members: the repulsion term is
-    the sharded kernel (global value, gradients for the local members), the per-member means of the data term and of
-    the L2 term are rescaled from M / G members to M.  No gradient all-reduce exists or is needed - members share no
-    weights - so the only exchange is the Gram column slices inside the kernel.  Unlike the reference's DDP (per-rank
-    sub-batch Grams) the loss is the single-GPU loss.  Member-coupled OOD losses (`mean_softmax_entropy`
-    averages the members' softmax) are refused."""
+    """Member-sharded TRAINING (last sentence; BASELINE configs[4]).  Every rank holds M / G members on the
+    full batch - the rank's own members of a fixed ensemble (`ensemble_size` = `num` = M / G), or its slice of the members
+    a hypernetwork samples this step (`sample_member_latents`) - and calls `shard_method` once on its `repulsive_kernel` /
+    `mle` method (built with `num` = M / G).  After that rank r's loss is
+        beta CE(own members) / G + gamma rep(ALL members) [+ gamma_ood rep_ood(ALL members) + beta_ood H(ALL members)]
+    and its backward leaves on whatever produced the local members' parameters exactly the part of the unsharded step's
+    gradient that flows through those members: the repulsion terms are the sharded kernels (global value, gradients for the
+    local members; linear, cossim and rbf Grams), the OOD entropy of the member-averaged softmax is made exact by one tiny
+    all-reduce of the softmax sums (`ShardedMeanSoftmaxEntropy`), the per-member means of the data and L2 terms are
+    rescaled from M / G members to M.
+      * fixed ensembles: members share no weights - no gradient exchange exists or is needed;
+      * hypernetworks: the generator's weights are shared by all members, so after `loss.backward()` the generator
+        gradients of the ranks are summed with `allreduce_gradients(hyper)` (ONE flat bucket over RCCL).
+    Unlike the reference's DDP (per-rank sub-batch Grams; hyper/experiments/training.py:686-695) the loss is
+    the single-GPU loss.  Learnable method parameters (gamma, beta) are refused: their gradients mix global and local terms."""
+    from .diversity.losses import InlierOutlierEntropy, MeanSoftmaxEntropy
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if getattr(method, 'ood_loss', None) is not None:
-        raise NotImplementedError('shard_method: the OOD prediction loss averages over all members; not sharded')
+    if world > 1 and any(p.requires_grad for n, p in method.named_parameters() if n in ('gamma', 'gamma_ood', 'beta_ind', 'beta_ood')):
+        raise NotImplementedError('shard_method: learnable gamma / beta are not sharded')
+    ood = getattr(method, 'ood_loss', None)
+    if ood is not None and not isinstance(ood, ShardedMeanSoftmaxEntropy):
+        if not isinstance(ood, MeanSoftmaxEntropy):
+            raise NotImplementedError('shard_method: OOD loss %s is not sharded' % type(ood).__name__)
+        method.ood_loss = ShardedMeanSoftmaxEntropy(group)
     for name in ('model_kernel', 'model_kernel_ood'):
         kern = getattr(method, name, None)
         if kern is not None and not isinstance(kern, ShardedModelLayersKernel):
             setattr(method, name, ShardedModelLayersKernel(kern, group, backend))
-    if method.ind_loss is not None and not isinstance(method.ind_loss, _ScaledLoss):
-        method.ind_loss = _ScaledLoss(method.ind_loss, 1.0 / world)
+    if method.ind_loss is not None and not isinstance(method.ind_loss, (_ScaledLoss, _ShardedInlierOutlierEntropy)):
+        if isinstance(method.ind_loss, InlierOutlierEntropy):
+            method.ind_loss = _ShardedInlierOutlierEntropy(method.ind_loss, world, group)
+        else:
+            method.ind_loss = _ScaledLoss(method.ind_loss, 1.0 / world)
         if method.l2_reg is not None:
             method.l2_reg = method.l2_reg / world
     return method
+
+
+def sample_member_latents(hyper, members, device, group=None):
+    """This rank's slice of the `members` latent samples of a hypernetwork step: rank 0 draws them all
+    (`hyper.sample_params`, hyper/generators/mlp.py:42-44), broadcasts the small [members, latent] tensor, and every rank
+    keeps rows [r M / G, (r + 1) M / G) - the same members, in the same order, as the unsharded step would sample."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if members % world:
+        raise ValueError('%d sampled members do not shard over %d ranks' % (members, world))
+    z = hyper.sample_params(members, device=device)
+    if world > 1:
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        _sent(z.numel() * z.element_size() if rank == 0 else 0)
+        if _staged(group, z):
+            h = z.cpu()
+            dist.broadcast(h, src, group=group)
+            z.copy_(h)
+        else:
+            dist.broadcast(z, src, group=group)
+    ml = members // world
+    return z[rank * ml:(rank + 1) * ml]
+
+
+def allreduce_gradients(module, group=None):
+    """Sum the gradients of a module's parameters over the ranks in ONE flat bucket (the hypernetwork's generator weights are
+    shared by the members every rank holds; replaces DistributedDataParallel's bucketed all-reduce of the reference,
+    hyper/experiments/training.py:693, for the member-sharded step).  Parameters without a gradient count as zero."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    params = [p for p in module.parameters() if p.requires_grad]
+    if world == 1 or not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    _all_reduce(flat, group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

@@ -75,6 +75,13 @@ class Yardstick:
     2.2e-5 against 2.0e-5.  HECKA_YARD_REPORT=1 prints every comparison instead of asserting."""
 
     RTOL = 1e-5
+    CEILING = 5e-5      # no group bound is ever looser than this, whatever the reference's float32 run did (measured
+    # worst group: 2 x 2.0e-5 = 4e-5, the MNIST hypernetwork's gradients).  Per-KEY bounds were tried and are wrong here:
+    # the float32 deviations of one step's gradients are not independent - the rounding of the few scalars at the head of
+    # the backward chain (loss terms, cosines next to 1) scales every gradient behind them - so a key where the reference's
+    # float32 run happened to land close says nothing about that key's conditioning (39 of 386 comparisons would fail a
+    # per-key 2 x bound while sitting at half their group's).  Instead every comparison that uses more than 1e-5 is
+    # recorded in `relaxed` and printed, so each relaxation is explicit.
 
     def __init__(self, name):
         import numpy as np
@@ -99,12 +106,18 @@ class Yardstick:
         return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
     def tol(self, key):
-        return max(self.RTOL, 2.0 * self.group_err[self.group(key)])
+        return max(self.RTOL, min(2.0 * self.group_err[self.group(key)], self.CEILING))
 
     def check(self, key, got, want=None, err=None):
         """got vs the float64 fixture entry `key` (or `want`), max-norm relative (or a caller-computed `err`)."""
         if err is None:
             err = self.rel(got, self.z64[key] if want is None else want)
+        if err > self.RTOL:      # a comparison that needs the relaxed bound: on record, and visible in the test's output
+            if not hasattr(self, 'relaxed'):
+                self.relaxed = []
+            self.relaxed.append((key, err))
+            print('YARD relaxed %s %s: %.2e > 1e-5 (reference float32: %.2e, bound %.2e)'
+                  % (self.name, key, err, self.ref_err.get(key, float('nan')), self.tol(key)))
         if self.report:
             print('YARD %-22s %-60s hip %.2e  ref_f32 %.2e  tol %.2e %s' % (self.name, key, err, self.ref_err.get(key, float('nan')),
                                                                           self.tol(key), 'FAIL' if err > self.tol(key) else ''))

@@ -219,6 +219,29 @@ def test_generator_mlp_runs_on_libhecka_kernels():
 
 
 @pytest.mark.gpu
+def test_groupnorm_frozen_weight_still_trains_the_bias():
+    """nn.GroupNorm gives a trainable bias its gradient when the weight is frozen; so must the fused kernel's node."""
+    from hyper_amd.net import hip
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    gn = hip.GroupNorm(4, 32, fused_gelu=True).to(dev)
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.2)
+        gn.bias.normal_(0.0, 0.2)
+    gn.weight.requires_grad_(False)
+    x = torch.randn(9, 32, device=dev, requires_grad=True)
+    gn(x).square().sum().backward()
+    assert gn.weight.grad is None and gn.bias.grad is not None
+    ref = torch.nn.GroupNorm(4, 32).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in gn.state_dict().items()})
+    ref.weight.requires_grad_(False)
+    xd = x.detach().cpu().double().requires_grad_(True)
+    torch.nn.functional.gelu(ref(xd)).square().sum().backward()
+    assert float((gn.bias.grad.cpu().double() - ref.bias.grad).abs().max()) <= 2e-5 * float(ref.bias.grad.abs().max())
+    assert float((x.grad.cpu().double() - xd.grad).abs().max()) <= 2e-5 * float(xd.grad.abs().max())
+
+
+@pytest.mark.gpu
 def test_graphed_hypernetwork_step_samples_members_inside_the_capture():
     """GraphedTrainStep with an int member count: latents are drawn inside the captured step (fresh ones every replay),
     the spectral-norm buffers keep iterating, the loss stays finite and the weights move."""
@@ -243,3 +266,84 @@ def test_graphed_hypernetwork_step_samples_members_inside_the_capture():
     assert len(set(losses)) == 4                      # new latents every replay
     assert not torch.equal(w0, hyper.code_gen.input.linear.weight_orig)
     assert not torch.equal(u0, hyper.code_gen.input.linear.weight_u)
+
+
+# ---- BASELINE configs[4] / VERDICT row n2: the hypernetwork step with the SAMPLED members sharded over ranks -------------
+def _sharded_hyper_worker(rank, world, port, name, out):
+    """One rank of the member-sharded hypernetwork step, rehearsed on one card (gloo rendezvous, collectives staged
+    through the host): the rank's slice of the fixture's latents -> generator -> batched target -> sharded method ->
+    backward -> ONE all-reduce of the generator gradients."""
+    root = os.path.dirname(HERE)
+    sys.path[:0] = [root, os.path.join(root, 'he-cka-ensembles_amd'), HERE, os.path.join(HERE, 'golden')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hyper_amd import parallel
+    from hyper_amd.diversity.methods import build_method
+    dev = torch.device('cuda:0')
+    gold, cfg, hyper = _build(torch.float32, name)
+    fill_state(hyper, json.loads(str(gold['stats'])))
+    hyper = hyper.to(dev).train()
+    Zall = torch.from_numpy(gold['Z']).float().to(dev)
+    M = Zall.shape[0]
+    ml = M // world
+
+    class _Fixed(object):           # rank 0's draw IS the fixture's latents
+        def sample_params(self, size, device=None):
+            return Zall.clone() if rank == 0 else torch.zeros_like(Zall)
+    Z = parallel.sample_member_latents(_Fixed(), M, dev)
+    assert torch.equal(Z, Zall[rank * ml:(rank + 1) * ml])
+    method = parallel.shard_method(build_method(dict(cfg['method'], num=ml)).to(dev))
+    X = torch.from_numpy(gold['X']).float().to(dev)
+    Y = torch.from_numpy(gold['Y']).to(dev)
+    ood = int(gold['ood_N'])
+    track = hyper(params=hyper.forward_params(Z), x=X, sample_params=False, ret_params=True, feature_split=True, ood_N=ood)
+    track = method(types.SimpleNamespace(training=True), track['params'], [], track, X[:-ood], Y, step=int(gold['step']))
+    track['loss'].backward()
+    parallel.allreduce_gradients(hyper)
+    torch.cuda.synchronize()
+    res = {'pred': track['pred'].detach().cpu()}
+    for key in ('ind_loss', 'ood_loss', 'ind_rep_loss', 'ood_rep_loss'):
+        if track.get(key) is not None:
+            res[key] = float(track[key].detach())
+    if rank == 0:
+        res['digests'] = {k: grad_digest(k, v.grad) for k, v in hyper.named_parameters()}
+    torch.save(res, '%s.%d' % (out, rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,world', [('hyper_train_step', 2), ('hyper_toy_train_step', 3), ('hyper_cifar_train_step', 2)])
+def test_member_sharded_hypernetwork_step_matches_reference(name, world, tmp_path):
+    """The sampled members sharded over `world` ranks (each rank: its slice of the latents through the replicated
+    generator, its members on the full batch, the inlier and outlier cossim / rbf HE kernels and the member-averaged OOD
+    entropy evaluated over ALL members through hyper_amd.parallel) and the generator gradients summed in one bucket:
+    predictions, loss terms and every generator gradient equal the REAL reference's unsharded step (the same fixtures and
+    yardstick as test_hypernetwork_train_step_matches_reference)."""
+    import torch.multiprocessing as mp
+    gold = np.load(os.path.join(GOLDEN, name + '_f64.npz'), allow_pickle=False)
+    f32 = np.load(os.path.join(GOLDEN, name + '_f32.npz'), allow_pickle=False)
+    out = str(tmp_path / 'hyper')
+    port = 29400 + (os.getpid() + 13 * world + len(name)) % 200
+    mp.start_processes(_sharded_hyper_worker, args=(world, port, name, out), nprocs=world, join=True, start_method='spawn')
+    res = [torch.load('%s.%d' % (out, r), weights_only=False) for r in range(world)]
+    yard = Yardstick(name)
+    yard.check('pred', torch.cat([r['pred'] for r in res]).numpy())
+    for key in ('ood_loss', 'ind_rep_loss', 'ood_rep_loss'):      # global terms: the same value on every rank
+        if key in gold.files:
+            for r in res:
+                yard.check(key, r[key])
+    yard.check('ind_loss', sum(r['ind_loss'] for r in res))        # the ranks' shares (already / G) add up to the mean
+
+    def digest_err(got, want, n):
+        scale = max(want[0], 1e-300)
+        return max(abs(got[0] - want[0]) / scale, abs(got[1] - want[1]) / (scale * np.sqrt(n)),
+                   np.abs(got[2:] - want[2:]).max() / max(np.abs(want[2:]).max(), scale / np.sqrt(n)))
+    _, _, hyper = _build(torch.float32, name)
+    sizes = {k: v.numel() for k, v in hyper.named_parameters()}
+    yard.group_err['g:'] = max(digest_err(f32['g:' + k], gold['g:' + k], n) for k, n in sizes.items())
+    worst = 0.0
+    for k, n in sizes.items():
+        worst = max(worst, yard.check('g:' + k, None, err=digest_err(res[0]['digests'][k], gold['g:' + k], n)))
+    print('sharded hypernetwork step (%d ranks): worst gradient digest error %.2e' % (world, worst))

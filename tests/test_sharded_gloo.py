@@ -134,3 +134,57 @@ def test_slice_bounds():
     assert b[0] == 0 and b[-1] == 1600 and all(x % 64 == 0 for x in b) and b == sorted(b)
     assert slice_bounds(7 * 7, 2, 64) == [0, 24, 49]        # not a multiple of the granule: element granularity
     assert slice_bounds(64, 4, 64) == [0, 0, 0, 0, 64]      # fewer chunks than ranks: empty slices
+
+
+# ---- pieces of the member-sharded HYPERNETWORK step (shared generator weights): latent broadcast, the exact member-averaged
+# OOD entropy, the flat-bucket gradient all-reduce - with a small shared-weight torch generator standing in for the MLP
+def _gen_case():
+    torch.manual_seed(5)
+    gen = torch.nn.Linear(5, 12).double()
+    X = torch.randn(7, 4, dtype=torch.float64)
+    Y = torch.randint(0, 3, (7,))
+    return gen, X, Y
+
+
+def _gen_loss(gen, z, X, Y, members_total, entropy, ce_scale):
+    import torch.nn.functional as F
+    W = gen(z).view(z.shape[0], 4, 3)
+    pred = torch.einsum('bi,mio->mbo', X, W)
+    ce = F.cross_entropy(pred.reshape(-1, 3), Y.repeat(z.shape[0]))
+    return ce_scale * ce + 0.7 * entropy(z.shape[0], None, pred, None)
+
+
+def _gen_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'he-cka-ensembles_amd'), os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hyper_amd import parallel
+    gen, X, Y = _gen_case()
+
+    class Hyper(object):
+        def sample_params(self, size, device=None):
+            torch.manual_seed(77 + rank)          # ranks would draw DIFFERENT latents: rank 0's draw must win
+            return torch.randn(size, 5, dtype=torch.float64)
+    z = parallel.sample_member_latents(Hyper(), 6, 'cpu')
+    loss = _gen_loss(gen, z, X, Y, 6, parallel.ShardedMeanSoftmaxEntropy(), 1.0 / world)
+    loss.backward()
+    parallel.allreduce_gradients(gen)
+    torch.save({'z': z, 'grads': [p.grad for p in gen.parameters()]}, '%s.%d' % (out, rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_generator_pieces_match_single_process(world, tmp_path):
+    from hyper_amd.diversity.losses import MeanSoftmaxEntropy
+    out = str(tmp_path / 'gen')
+    port = 29300 + (os.getpid() + 5 * world) % 200
+    mp.start_processes(_gen_worker, args=(world, port, out), nprocs=world, join=True, start_method='spawn')
+    gen, X, Y = _gen_case()
+    torch.manual_seed(77)
+    z = torch.randn(6, 5, dtype=torch.float64)
+    _gen_loss(gen, z, X, Y, 6, MeanSoftmaxEntropy(), 1.0).backward()
+    res = [torch.load('%s.%d' % (out, r), weights_only=True) for r in range(world)]
+    assert torch.equal(torch.cat([r['z'] for r in res]), z)
+    for r in res:       # every rank ends with the unsharded step's generator gradients
+        for g, p in zip(r['grads'], gen.parameters()):
+            assert float((g - p.grad).abs().max()) <= 1e-12 * float(p.grad.abs().max())
