@@ -69,10 +69,16 @@ struct H32Smem {
 // Pro: prefetch(SET, k) once per k-tile, a whole k-tile before its values are staged (SET = the tile's parity; k = the
 // first of the four k this thread stages of a k-contiguous operand), stageA(SET, quad, i) / stageB(SET, quad, i) on
 // the staged fp32 values (i: the thread's i-th row of the tile).
-template <int TM, int TN, bool NN, class Pro, bool FOLD = true, bool SAMEAB = false, bool ASLICED = false, int NT = kThreads>
+// ASHARE (NT products, TN = 2 TM): the B panel is TWO blocks of TM rows (the second starts `b_skip` bytes behind where
+// it would lie if the panel were contiguous) and the A rows ARE one of them (panel rows a_share_row ..): A is neither
+// loaded nor staged, its fragments are read from B's LDS image.  The paired tiles of the symmetric Gram
+// (gram_center_pair_body): a diagonal block and a neighbour for the price of the neighbour's panel.
+template <int TM, int TN, bool NN, class Pro, bool FOLD = true, bool SAMEAB = false, bool ASLICED = false, int NT = kThreads,
+          bool ASHARE = false>
 struct GemmTileH32 {
   static_assert(NT == 2 * TN && (NT == 256 || NT == 512), "one thread per column and k-half of the NN operand");
   static_assert(!SAMEAB || (!NN && TM == TN), "SAMEAB: NT product with a square tile");
+  static_assert(!ASHARE || (!NN && !SAMEAB && !ASLICED && TN == 2 * TM), "ASHARE: NT product, B panel of two A-sized blocks");
   static constexpr int RPK = NT / 8;            // rows of a k-contiguous operand staged per pass (8 lanes: one 128-byte row)
   static constexpr int WCOLS = NT / 128;
   static constexpr int WM = TM / 2, WN = TN / WCOLS, MI = WM / 16, NI = WN / 16;
@@ -86,7 +92,7 @@ struct GemmTileH32 {
 
   __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb, unsigned bytesB,
                                       int ldb, int row0, int col0, int kbeg, int kend, Pro& pro, int a_rshift = 31,
-                                      unsigned a_blk = 0) {
+                                      unsigned a_blk = 0, unsigned b_skip = 0, int a_share_row = 0) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS, r16 = lane & 15, g = lane >> 4;
     f32x4 loc[MI][NI];   // (unused and optimised away without FOLD)
@@ -131,6 +137,7 @@ struct GemmTileH32 {
     f32x4 ra[CA], rb[CB];   // one k-tile (NN: quad i = k-row krow + 8 i)
     // quad i of tile kt (B: index into rb)
     auto gload_a = [&](int i, int kt) __attribute__((always_inline)) {
+      if (ASHARE) return;
       const unsigned so = sA0 + (unsigned)(kt * kH32BK) * 4u;
       ra[i] = __builtin_bit_cast(f32x4, ASLICED ? __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[ASLICED ? i : 0], (int)so, 0)
                                                 : __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[0], (int)(so + i * stepA), 0));
@@ -141,7 +148,8 @@ struct GemmTileH32 {
         const int so = (int)(sB0 + (unsigned)(kt * kH32BK + krow + 8 * i) * ldb * 4u);
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so, 0));
       } else {
-        const int so = (int)(sB0 + (unsigned)(kt * kH32BK) * 4u);
+        // (b_skip: the panel's second half may be another block of rows - non-zero for the paired Gram tiles only)
+        const int so = (int)(sB0 + (unsigned)(kt * kH32BK) * 4u + (2 * i >= CB ? b_skip : 0u));
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so + (int)(i * stepB), 0));
       }
     };
@@ -162,7 +170,7 @@ struct GemmTileH32 {
     };
     auto stage_all = [&](auto SET, int st) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < CA; ++i) {
+      for (int i = 0; i < (ASHARE ? 0 : CA); ++i) {
         u32x2 p[2];
         pro.stageA(SET, ra[i], i);
         split2h(ra[i], 0, p[0], p[1], 0);
@@ -198,14 +206,18 @@ struct GemmTileH32 {
 
     // fragment registers: A in two buffers of (h, l), B as NI x (two slots): B.h of tile kt in slot kt & 1, B.l in the other
     f16x8 afr[2][2], bfr[NI][2];
-    const int fa = (wr * WM + r16) * 32 + ((g ^ h32_swz(r16)) * 8);
+    const int fa = ((ASHARE ? a_share_row : 0) + wr * WM + r16) * 32 + ((g ^ h32_swz(r16)) * 8);
+    auto& sma = *[&]() {      // ASHARE: A's fragments come from B's image
+      if constexpr (ASHARE) return &sm.b;
+      else return &sm.a;
+    }();
     // NN: ds_read_b64_tr_b16 - lane 4 q + p of 16-lane group g addresses k-row 8 g + 4 e + q, columns 4 p .. 4 p + 3 of
     // the block's panel, and receives its column's four k (e = 0, 1: the two halves of the lane's eight k)
     const int fb = NN ? ((wc * WN) / 16) * kH32Panel + (((lane >> 2) & 3) + 4 * (g & 1) + 16 * (g >> 1)) * 16 + (lane & 3) * 4
                       : (wc * WN + r16) * 32 + ((g ^ h32_swz(r16)) * 8);
     auto rd_a = [&](int st, int blk, int buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int p = 0; p < 2; ++p) afr[buf][p] = *reinterpret_cast<const f16x8*>(&sm.a[st][p][fa + blk * 512]);
+      for (int p = 0; p < 2; ++p) afr[buf][p] = *reinterpret_cast<const f16x8*>(&sma[st][p][fa + blk * 512]);
     };
     auto rd_b = [&](int st, int plane, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -249,7 +261,7 @@ struct GemmTileH32 {
         constexpr int r = decltype(R)::value;
         constexpr bool isA = r < 2 * CA;
         constexpr int quad = (isA ? r : r - 2 * CA) >> 1, step = r & 1;
-        if constexpr (isA || !SAMEAB) {
+        if constexpr ((isA && !ASHARE) || (!isA && !SAMEAB)) {
           if constexpr (step == 0) {
             if (more_s) {
               if constexpr (isA) {

@@ -92,6 +92,7 @@ struct Config {
   int bwd_tn;             // HECKA_BWD_TN      (256): column width of the all-layers dX tile (128: four waves)
   bool x16_exact;         // HECKA_X16_EXACT   (0): 16-bit features on the centred three-product Gram
   bool gram_nosplit;      // HECKA_GRAM_NOSPLIT (0): never split the all-layers Gram over K
+  bool gram_pair;         // HECKA_GRAM_PAIR   (1): all-layers Gram on the paired 128 x 256 tiles (0: 128 x 128 tiles)
 };
 static Config read_config() {
   auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; };
@@ -104,6 +105,7 @@ static Config read_config() {
   c.bwd_tn = (int)num("HECKA_BWD_TN", 256);
   c.x16_exact = getenv("HECKA_X16_EXACT") != nullptr;
   c.gram_nosplit = getenv("HECKA_GRAM_NOSPLIT") != nullptr;
+  c.gram_pair = num("HECKA_GRAM_PAIR", 1) != 0;
   return c;
 }
 static Config g_config = read_config();
@@ -618,6 +620,91 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
   });
 }
 
+// ---- Paired tiles of the symmetric Gram (f16x3 on the 32-deep tile, fp32 features, interior shapes) -----------------------
+// A 128 x 128 tile stages 256 rows per k-tile for one block of the Gram (128 for a diagonal block); the launch is bound by
+// that path, not by the matrix cores.  Here a workgroup of eight waves computes TWO blocks of one block
+// row, K[I][J0] and K[I][J1], from one A panel (block I) and one B panel (blocks J0 and J1): 384 staged rows for two
+// blocks - and when I is one of J0 / J1 (every tile but one per pairing of B = 512) the A rows are read from B's LDS
+// image: 256 rows.  Per member and k-tile the upper triangle of B = 512 costs 1536 staged rows instead of 2048.  The
+// tiles of a member are a host-built table (gram_pair_tiles): blocks of a block row paired left to right, the blocks a
+// row leaves over (all in the last block column) paired through the transpose, a last odd one computed twice.
+struct GramPairTiles {
+  unsigned char t[32][3];   // (I, J0, J1) per tile, heaviest (no shared panel) first
+  int n;
+};
+
+template <bool ASHARE>
+__device__ __forceinline__ void gram_center_pair_run(GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, false>& out,
+                                                     H32Smem<128, 256, false>& sm, const char* Xm, unsigned bytes, int P, int I,
+                                                     int J0, int J1, int kbeg, int kend, CenterProK32& pro) {
+  using Tile = GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, ASHARE>;
+  Tile tile;
+  const unsigned skip = (unsigned)(J1 - J0 - 1) * 128u * (unsigned)P * 4u;     // (unsigned wrap-around for J1 <= J0 is intended)
+  tile.run(sm, Xm, bytes, P, Xm, bytes, P, I * 128, J0 * 128, kbeg, kend, pro, 31, 0u, skip, I == J0 ? 0 : 128);
+#pragma unroll
+  for (int i = 0; i < Tile::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < Tile::NI; ++j) out.acc[i][j] = tile.acc[i][j];
+}
+
+__device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X, const float* __restrict__ sbar,
+                                                      const float* __restrict__ xmax, float* __restrict__ C,
+                                                      float* __restrict__ cvec, int B, int P, const GramPairTiles& tiles,
+                                                      int xcd_map, int w, int kbeg, int kend, int slice_rshift, int Mlay) {
+  using Tile = GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, false>;
+  __shared__ H32Smem<128, 256, false> sm;
+  __shared__ float cA[128], cB[256];
+  int m, rem;
+  member_tile_w(w, tiles.n, xcd_map, m, rem);
+  // (kernel-argument table indexed with a runtime index: scalar selects)
+  int I = tiles.t[0][0], J0 = tiles.t[0][1], J1 = tiles.t[0][2];
+#pragma unroll
+  for (int i = 1; i < 32; ++i)
+    if (i == rem) { I = tiles.t[i][0]; J0 = tiles.t[i][1]; J1 = tiles.t[i][2]; }
+  const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * 4u;
+  CenterProK32 pro;
+  pro.sbar = sbar + (size_t)m * P;
+  pro.s = pow2_scale(xmax[m], 13);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pro.cav[i] = pro.cbv[i] = 0.f;
+  const float unscale = 1.0f / (pro.s * pro.s);
+  const bool share = I == J0 || I == J1;
+  Tile tile;
+  if (share) gram_center_pair_run<true>(tile, sm, Xm, (unsigned)B * P * 4u, P, I, J0, J1, kbeg, kend, pro);
+  else gram_center_pair_run<false>(tile, sm, Xm, (unsigned)B * P * 4u, P, I, J0, J1, kbeg, kend, pro);
+  // c_b = sbar . (x_b - sbar): eight consecutive lanes share a staged row; thread t staged A rows (t >> 3) + 64 i, i < 2,
+  // and B panel rows (t >> 3) + 64 i, i < 4
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = pro.cav[i], b = pro.cbv[i];
+#pragma unroll
+    for (int d = 1; d < 8; d *= 2) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if ((threadIdx.x & 7) == 0) {
+      if (i < 2 && !share) cA[(threadIdx.x >> 3) + 64 * i] = a;
+      cB[(threadIdx.x >> 3) + 64 * i] = b;
+    }
+  }
+  __syncthreads();
+  if (share && threadIdx.x < 128) cA[threadIdx.x] = cB[(I == J0 ? 0 : 128) + threadIdx.x];
+  __syncthreads();
+  const size_t mstride = slice_rshift < 31 ? ((size_t)B << slice_rshift) : (size_t)B * B;
+  const size_t blk = slice_rshift < 31 ? (size_t)Mlay * mstride : 0;
+  const unsigned rmask = slice_rshift < 31 ? (1u << slice_rshift) - 1u : 0x7fffffffu;
+  float* Cm = C + (size_t)m * mstride;
+  auto at = [&](int row, int col) -> float& {
+    return Cm[(size_t)((unsigned)row >> slice_rshift) * blk + (size_t)((unsigned)row & rmask) * B + col];
+  };
+  const int row0 = I * 128;
+  if (share && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];   // block I's diagonal tile is this one
+  tile.for_each([&](int lr, int lc, float v) {
+    const int J = lc < 128 ? J0 : J1;
+    const int col = J * 128 + (lc & 127);
+    v *= unscale;
+    at(row0 + lr, col) = v + cB[lc];
+    if (I != J) at(col, row0 + lr) = v + cA[lr];
+  });
+}
+
 template <int SCHEME, bool RAGGED = false>
 __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_kernel(const float* __restrict__ X,
                                                                      const float* __restrict__ sbar,
@@ -712,6 +799,38 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
   const int mblk = nsplit > 1 ? a.M : a.Mblk;
   if constexpr (RAW) gram_raw_x6_body<EX>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend);
   else gram_center_x6_body<SCHEME, EX, RAGGED, K32>(X, sbar, xmax, C, cvec, B, P, ntile, xcd_map, wl, kbeg, kend, slice_rshift, mblk);
+}
+
+// The all-layers launch on the paired tiles (gram_center_pair_body): same layer table, split-K slabs and slice-major
+// epilogue as gram_center_x6_multi_kernel, 512 threads, one workgroup per CU.
+__global__ __launch_bounds__(512, 1) void gram_center_pair_multi_kernel(GramMultiArgs a, GramPairTiles tiles, int B, int xcd_map,
+                                                                         int slice_rshift) {
+  const int w = blockIdx.x;
+  int li = 0, w0 = 0;
+  while (li + 1 < a.L && w >= a.l[li].wg_end) {
+    w0 = a.l[li].wg_end;
+    ++li;
+  }
+  const void* X = a.l[0].X; const float* sbar = a.l[0].sbar; const float* xmax = a.l[0].xmax;
+  float* C = a.l[0].C; float* cvec = a.l[0].cvec; int P = a.l[0].P;
+  int nsplit = a.l[0].nsplit, kchunk = a.l[0].kchunk; float* Cws = a.l[0].Cws; float* cws = a.l[0].cws;
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) {
+      X = a.l[i].X; sbar = a.l[i].sbar; xmax = a.l[i].xmax; C = a.l[i].C; cvec = a.l[i].cvec; P = a.l[i].P;
+      nsplit = a.l[i].nsplit; kchunk = a.l[i].kchunk; Cws = a.l[i].Cws; cws = a.l[i].cws;
+    }
+  int wl = w - w0, kbeg = 0, kend = P;
+  if (nsplit > 1) {
+    const int per = a.M * tiles.n;
+    const int z = wl / per;
+    wl -= z * per;
+    kbeg = z * kchunk;
+    kend = kbeg + kchunk < P ? kbeg + kchunk : P;
+    C = Cws + (size_t)z * a.M * B * B;
+    cvec = cws + (size_t)z * a.M * B;
+  }
+  gram_center_pair_body(X, sbar, xmax, C, cvec, B, P, tiles, xcd_map, wl, kbeg, kend, slice_rshift, nsplit > 1 ? a.M : a.Mblk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2878,6 +2997,30 @@ int hecka_gram_center_multi_x16(int L, const void* const* X, int dtype, const fl
   return gram_center_multi_impl(L, X, dtype, sbar, xmax, M, B, P, C, cvec, ws, ws_bytes, slice_rows, slice_members, gemm_mode, stream);
 }
 
+// Tiles (I; J0, J1) that cover the upper triangle of an n x n block matrix two blocks at a time (GramPairTiles): the
+// blocks of block row I paired left to right; a row's odd last block lies in column n - 1 - those are paired through the
+// transpose as (n - 1; I_a, I_b); a last odd one is computed twice.  Tiles that share no panel (heaviest) come first.
+static GramPairTiles gram_pair_tiles(int n) {
+  GramPairTiles t;
+  t.n = 0;
+  unsigned char shared[32][3];
+  int ns = 0, left[8], nl = 0;
+  auto put = [&](int I, int J0, int J1) {
+    if (I == J0 || I == J1) { shared[ns][0] = (unsigned char)I; shared[ns][1] = (unsigned char)J0; shared[ns][2] = (unsigned char)J1; ++ns; }
+    else { t.t[t.n][0] = (unsigned char)I; t.t[t.n][1] = (unsigned char)J0; t.t[t.n][2] = (unsigned char)J1; ++t.n; }
+  };
+  for (int I = 0; I < n; ++I) {
+    int J = I;
+    for (; J + 1 < n; J += 2) put(I, J, J + 1);
+    if (J < n) left[nl++] = I;          // block (I, n - 1)
+  }
+  for (int k = 0; k + 1 < nl; k += 2) put(n - 1, left[k], left[k + 1]);
+  if (nl % 2) put(n - 1, left[nl - 1], left[nl - 1]);
+  for (int k = 0; k < ns; ++k, ++t.n) { t.t[t.n][0] = shared[k][0]; t.t[t.n][1] = shared[k][1]; t.t[t.n][2] = shared[k][2]; }
+  for (int k = t.n; k < 32; ++k) { t.t[k][0] = t.t[0][0]; t.t[k][1] = t.t[0][1]; t.t[k][2] = t.t[0][2]; }
+  return t;
+}
+
 static int gram_center_multi_impl(int L, const void* const* X, int dtype, const float* const* sbar,
                                   const float* const* xmax, int M, int B, const int* P, float* const* C,
                                   float* const* cvec, void* ws, size_t ws_bytes, int slice_rows, int slice_members, int gemm_mode,
@@ -2895,7 +3038,8 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   if (!X || !sbar || !P || !C || !cvec) return fail(HECKA_EINVAL, "gram_center_multi: null pointer%s");
   if (M <= 0 || B <= 0 || B % 4 != 0) return fail(HECKA_EINVAL, "%sgram_center_multi: needs B %% 4 == 0 (B = %lld)", "", B);
   if (g_gemm_mode == HECKA_GEMM_FP32) return fail(HECKA_EINVAL, "gram_center_multi: not available in HECKA_GEMM_FP32 mode%s");
-  const int ntile = (B + 127) / 128, per = M * (ntile * (ntile + 1) / 2);
+  const int ntile = (B + 127) / 128;
+  int per = M * (ntile * (ntile + 1) / 2);
   bool ragged = B % 128 != 0;      // any layer off the interior shape: the whole launch takes the masked tile
   bool have_max = xmax != nullptr;
   GramMultiArgs a;
@@ -2913,6 +3057,16 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   if (need > ws_bytes) return fail(HECKA_EWORKSPACE, "%sgram_center_multi: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
   if (!need)
     for (int i = 0; i < L; ++i) { nsp[i] = 1; kch[i] = P[i]; }
+  // paired 128 x 256 tiles (gram_center_pair_body): fp32 features, interior shapes, f16x3 on the 32-deep tile
+  bool pair = dtype == HECKA_DT_F32 && !ragged && xmax && g_gemm_mode == HECKA_GEMM_AUTO && k32_wanted() && config().gram_pair &&
+              ntile >= 2 && ntile <= 8;
+  for (int i = 0; i < L && pair; ++i) pair = xmax[i] && P[i] % 32 == 0 && kch[i] % 32 == 0;
+  GramPairTiles tiles;
+  tiles.n = 0;
+  if (pair) {
+    tiles = gram_pair_tiles(ntile);
+    per = M * tiles.n;
+  }
   float* wsp = static_cast<float*>(ws);
   bool any_split = false;
   long long wg = 0;
@@ -2953,6 +3107,8 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
     if (!have_max) return fail(HECKA_EINVAL, "gram_center_multi: ragged shapes need xmax%s");
     hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, true>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B,
                        ntile, xcd, rs);
+  } else if (pair) {
+    hipLaunchKernelGGL(gram_center_pair_multi_kernel, dim3((unsigned)wg), dim3(512), 0, st, a, tiles, B, xcd, rs);
   } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO) {
     bool k32 = k32_wanted();
     for (int i = 0; i < L; ++i) k32 = k32 && P[i] % 32 == 0 && kch[i] % 32 == 0;

@@ -116,3 +116,30 @@ def test_sampler_torch_pieces_match_the_hip_ones(monkeypatch):
         outs.append([y.detach(), xx.grad] + [p.grad for p in b.parameters()] + [hip.matvec(Wm, v)])
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,B,Ps,rows', [(64, 512, (1024, 512), 0), (8, 512, (4096, 2048, 256), 64), (16, 256, (512, 256), 0),
+                                         (4, 768, (256, 128), 0), (3, 1024, (256, 128), 256), (5, 128, (256, 64), 0)])
+def test_paired_gram_tiles_match_the_square_ones(M, B, Ps, rows, monkeypatch):
+    """HECKA_GRAM_PAIR: the all-layers Gram on paired 128 x 256 tiles (two blocks of a block row per workgroup, the
+    diagonal block's rows read from its neighbour's panel) against the 128 x 128 tiles and against fp64 products - block
+    counts 1 (no pairing: the square tiles), 2 (one tile computed twice), 4 (the bench), 6, 8; split over K (8 members); the
+    slice-major epilogue."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(M * B)
+    Xs = [(torch.randn(M, B, p, device=dev) + 0.3 * i) * (1 + i) for i, p in enumerate(Ps)]
+    pair = ops.centered_gram_multi(Xs, slice_rows=rows)
+    monkeypatch.setenv('HECKA_GRAM_PAIR', '0')
+    square = ops.centered_gram_multi(Xs, slice_rows=rows)
+    for X, (C, cvec, xmax), (C0, cvec0, xmax0) in zip(Xs, pair, square):
+        assert torch.equal(xmax, xmax0)
+        assert float((C - C0).abs().max()) <= 2e-6 * float(C0.abs().max())
+        assert float((cvec - cvec0).abs().max()) <= 2e-6 * float(cvec0.abs().max())
+        Xd = X.double()
+        Kd = Xd @ Xd.transpose(1, 2)
+        Cd = Kd - Kd.mean(dim=2, keepdim=True)
+        if rows:
+            Cd = Cd.view(M, B // rows, rows, B).permute(1, 0, 2, 3)
+        assert float((C.double() - Cd).abs().max()) <= 5e-6 * float(Cd.abs().max())
