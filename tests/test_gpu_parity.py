@@ -257,6 +257,45 @@ def test_f16x3_scaling_over_dynamic_range():
     assert float(errd.max()) <= 1e-5, errd
 
 
+def test_f16x3_layer_gemms_over_dynamic_range():
+    """hecka_bgemm_x3_f32 and hecka_conv_x3_f32 take their power-of-two operand scales from max |W| and max |x| per
+    member: weights and activations spanning four decades INSIDE a member (elements below 2^-17 of the maximum keep
+    absolute, not relative, precision - include/hecka.h) and members eight decades apart stay at the fp32 tolerance,
+    measured per member against fp64 on that member's own largest output."""
+    import torch.nn.functional as F
+    from hyper_amd.layers.linear import _absmax_rows, _bgemm_x3, _x3_eligible
+    from hyper_amd.layers.conv import BatchedConv2d
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    batch, rows, cols, K = 4, 128, 256, 512
+    member = torch.tensor([1e-4, 1.0, 30.0, 1e4])[:, None, None]
+    A = torch.randn(batch, rows, K, generator=g) * (10.0 ** torch.linspace(-2, 2, K))[None, None, :] * member
+    Bm = torch.randn(batch, K, cols, generator=g) * (10.0 ** torch.linspace(2, -2, K))[None, :, None] / member
+    A, Bm = A.to(dev), Bm.to(dev)
+    assert _x3_eligible(batch, rows, cols, K)
+    out = _bgemm_x3(A, Bm, batch, rows, cols, K, rows * K, K * cols, True, 0.5, _absmax_rows(A.view(batch, -1), batch),
+                    _absmax_rows(Bm.view(batch, -1), batch), 1)
+    ref = 0.5 * (A.double() @ Bm.double())
+    err = (out.double() - ref).abs().amax(dim=(1, 2)) / ref.abs().amax(dim=(1, 2))
+    assert float(err.max()) <= 5e-6, err
+    # implicit-GEMM convolution (forward, input gradient, weight gradient) with the same spread in weights and activations
+    M, N, C, HW = 3, 8, 128, 16
+    x = torch.randn(M, N, C, HW, HW, generator=g) * (10.0 ** torch.linspace(-2, 2, C))[None, None, :, None, None]
+    x = (x * torch.tensor([1e-3, 1.0, 1e3])[:, None, None, None, None]).to(dev)
+    W = torch.randn(M, C, C, 3, 3, generator=g) * 0.05 * (10.0 ** torch.linspace(2, -2, C))[None, None, :, None, None]
+    W = (W * torch.tensor([1e2, 1.0, 1e-2])[:, None, None, None, None]).to(dev)
+    up = torch.randn(M, N, C, HW, HW, generator=g).to(dev)
+    xx, WW = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    y = BatchedConv2d.apply(xx, WW, None, 0.7, 1.0, (3, 3, 1, 1, 1, 1, 1, 1))
+    (y * up).sum().backward()
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    yd = torch.stack([F.conv2d(xd[m], 0.7 * Wd[m], None, 1, 1) for m in range(M)])
+    (yd * up.double()).sum().backward()
+    for name, got, want in (('y', y.detach(), yd.detach()), ('dx', xx.grad, xd.grad), ('dW', WW.grad, Wd.grad)):
+        e = (got.double() - want).flatten(1).abs().amax(dim=1) / want.flatten(1).abs().amax(dim=1)
+        assert float(e.max()) <= 1e-5, (name, e)
+
+
 @pytest.mark.parametrize('P,style', [(512, 'randn'), (2048, 'correlated')])
 def test_bench_shape_against_fp64_oracle_on_gpu(P, style):
     """Full bench member/sample counts (M=64, B=512) against the oracle evaluated in fp64 with stock
