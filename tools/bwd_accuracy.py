@@ -1,5 +1,5 @@
 """Error of hecka_gram_bwd_f32 (dX = W X) against fp64: max and mean of (result - exact) / sum_k |w x|.
-    python tools/bwd_accuracy.py B P      (env HECKA_BWD_FOLD=1 selects the local-chain variant; default for B <= 1024: one chain)"""
+    python tools/bwd_accuracy.py B P      (B <= 1024: one accumulation chain; above: 64-k local chains)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""Streaming self-pairwise kernel (pairwise_self64_kernel) against the tiled kernel and fp64, with timings.
+"""Streaming self-pairwise kernel (pairwise_self64_kernel; HECKA_PAIRWISE_X6=1: its bf16 six-product form) against fp64, with timings.
     python tools/pairwise_check.py [B ...]"""
 import os
 import subprocess
@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from hyper_amd import ops  # noqa: E402
 
 dev = torch.device('cuda:0')
-tiled = os.environ.get('HECKA_PAIRWISE_TILED') is not None
+x6 = os.environ.get('HECKA_PAIRWISE_X6') == '1'
 for B in [int(a) for a in sys.argv[1:]] or [512, 128, 64]:
     for K in (B * B, B * B // 8):
         if K % 32:
@@ -30,5 +30,5 @@ for B in [int(a) for a in sys.argv[1:]] or [512, 128, 64]:
             ops.pairwise_inner(C)
         e1.record()
         torch.cuda.synchronize()
-        print('%s K=%7d  rel err %.2e  asym %.1e  %.1f us' % ('tiled ' if tiled else 'stream', K, err, sym,
+        print('%s K=%7d  rel err %.2e  asym %.1e  %.1f us' % ('bf16x6' if x6 else 'f32   ', K, err, sym,
                                                                e0.elapsed_time(e1) / 20 * 1e3), flush=True)
