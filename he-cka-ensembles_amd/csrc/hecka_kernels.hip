@@ -87,6 +87,7 @@ struct Config {
   long long small_grid;   // HECKA_SMALL_GRID  (384): fewer 128-row tiles than this (1.5 per CU) -> 64-row fp32-MFMA tiles
   int ragged_x3;          // HECKA_RAGGED_X3   (-1 = by grid size): 1 / 0 ragged shapes always / never on the masked f16x3 tile
   bool combine_fixg;      // HECKA_COMBINE_FIXG (1): streaming combine keeps its strip's column terms in LDS
+  bool combine_x3;        // HECKA_COMBINE_X3 (1): all-layers combine on the fp16 matrix cores when the caller supplies nsq
   bool k32;               // HECKA_K32         (1): all-layers Gram / wide dX on the 32-deep 16x16x32 tile
   bool pairwise_x6;       // HECKA_PAIRWISE_X6 (0): streaming pairwise on the bf16 matrix cores (six-product split)
   int bwd_tn;             // HECKA_BWD_TN      (256): column width of the all-layers dX tile (128: four waves)
@@ -100,6 +101,7 @@ static Config read_config() {
   c.small_grid = num("HECKA_SMALL_GRID", 384);
   c.ragged_x3 = (int)num("HECKA_RAGGED_X3", -1);
   c.combine_fixg = num("HECKA_COMBINE_FIXG", 1) != 0;
+  c.combine_x3 = num("HECKA_COMBINE_X3", 1) != 0;
   c.k32 = num("HECKA_K32", 1) != 0;
   c.pairwise_x6 = num("HECKA_PAIRWISE_X6", 0) != 0;
   c.bwd_tn = (int)num("HECKA_BWD_TN", 256);
@@ -1112,14 +1114,26 @@ __device__ __forceinline__ float block_sum_f(float v, float* red) {   // 256-thr
 // column strip - wave w takes Gram rows, not chunks, in turn - so the column terms gamma[:, b] of the epilogue are the same
 // 64 x 64 block for every chunk: loaded into LDS once instead of 32 dependent 8-byte loads per chunk (226 -> 187 us for
 // the bench's five layers).
-template <int RB, bool FIXG = false>
+// X3 (the caller supplies nsq[j] = ||C_j||_F^2, the diagonal of the pairwise matrix): the 64-deep products on the fp16
+// matrix cores - v_mfma_f32_32x32x16_f16, three products hh + hl + lh of two-term fp16 splits, 48 MFMAs of 32 cycles per
+// chunk instead of 128 of 64, which takes the kernel off the fp32-MFMA floor (10.7 GFLOP at 157 TF = 68 us for the
+// bench's five layers) onto the HBM side.  Exact power-of-two scales: member row j of C by sc_j with sqrt(nsq_j) sc_j <=
+// 2^14 (|C_j[n]| <= ||C_j||_F), folded back into column j of A; row i of the folded A by ra_i with max_j |A'_ij| ra_i <=
+// 2^14, undone in the epilogue.  A is split once per workgroup into fragment-ordered planes in LDS; a lane splits the 64
+// elements of C it loads per chunk.  k-slot (g, e) of MFMA step s is member row 16 s + 2 e + g, so the loads are the same
+// row pairs (2 ks + h) as in the fp32 form and the blocked layouts need no more than their 8-row groups.
+template <int RB, bool FIXG = false, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __restrict__ A, const float* __restrict__ C,
-                                                                const float* __restrict__ gamma, int B, int detach_diag,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ nsq, int B, int detach_diag,
                                                                 float* __restrict__ W, long long N, long long chunk0,
                                                                 RowBlocks cb, RowBlocks wb) {
-  __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]
+  __shared__ float sA[32][RB][64];   // [k-step][row block][lane]: A[rb*32 + (lane & 31)][2 ks + (lane >> 5)]  (X3: scratch [i][j])
   __shared__ float sG[4][32 * RB];   // per wave: gamma[:, a] of the chunk's Gram row a
   __shared__ float sGC[FIXG ? 32 * RB : 1][FIXG ? 64 : 2];   // FIXG: gamma[:, b0 .. b0 + 63] of the workgroup's strip
+  __shared__ u32x4 sAx[X3 ? 2 : 1][X3 ? 4 : 1][X3 ? RB : 1][X3 ? 64 : 1];   // X3: [plane h / l][step][row block][lane] A fragments
+  __shared__ float sSC[2][X3 ? 32 : 1];     // X3: scale of member row 2 ks + h at [h][ks]
+  __shared__ float sRS[X3 ? 32 * RB : 1];   // X3: 2 / ra_i
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, j = lane & 31;
   // blockIdx.y: layer of a batched call (A [L,Ma,64], C [L,64,N], gamma [L,Ma,B], W [L,Ma,N] contiguous)
   // (cb / wb: the rows of C / W may lie in blocks - RowBlocks above; gamma and A are always [L, rows, .])
@@ -1127,9 +1141,42 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   C += (size_t)blockIdx.y * cb.lay;
   gamma += (size_t)blockIdx.y * (32 * RB) * B;
   W += (size_t)blockIdx.y * wb.lay;
-  for (int e = t; e < 32 * RB * 64; e += 256) {
-    const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
-    sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
+  if constexpr (X3) {
+    float* sAf = &sA[0][0][0];           // A'[i][j] = A_ij / sc_j, 64 floats per row
+    float* sRA = &sG[0][0];              // ra_i (sG is not used before the chunk loop)
+    nsq += (size_t)blockIdx.y * 64;
+    if (t < 64) sSC[t & 1][t >> 1] = pow2_scale(sqrtf(fmaxf(nsq[t], 0.f)), 14);
+    __syncthreads();
+    for (int e = t; e < 32 * RB * 64; e += 256) sAf[e] = A[e] * (1.0f / sSC[e & 1][(e & 63) >> 1]);
+    __syncthreads();
+    if (t < 32 * RB) {
+      float mx = 0.f;
+      for (int q = 0; q < 64; ++q) mx = fmaxf(mx, fabsf(sAf[t * 64 + ((q + t) & 63)]));
+      // (pow2_scale's exponent range of +-60 is meant for products of two scales; a row of A may lie further out)
+      const int be = (int)((__float_as_uint(mx) >> 23) & 0xFF);
+      int k = (be == 0 || be == 255) ? 0 : 14 - (be - 126);
+      k = k < -120 ? -120 : (k > 120 ? 120 : k);
+      sRA[t] = __uint_as_float((unsigned)(127 + k) << 23);
+      sRS[t] = __uint_as_float((unsigned)(128 - k) << 23);      // 2 / ra
+    }
+    __syncthreads();
+    for (int idx = t; idx < 4 * RB * 64 * 4; idx += 256) {
+      const int pq = idx & 3, l = (idx >> 2) & 63, rb = (idx >> 8) % RB, st = idx / (256 * RB);
+      const int i = rb * 32 + (l & 31), j0 = 16 * st + 4 * pq + (l >> 5);
+      const float ra = sRA[i];
+      const f32x2 x = {sAf[i * 64 + j0] * ra, sAf[i * 64 + j0 + 2] * ra};
+      const f16x2 hh = __builtin_convertvector(x, f16x2);
+      const f32x2 r = {x[0] - (float)hh[0], x[1] - (float)hh[1]};
+      const f16x2 ll = __builtin_convertvector(r, f16x2);
+      reinterpret_cast<unsigned*>(&sAx[0][st][rb][l])[pq] = __builtin_bit_cast(unsigned, hh);
+      reinterpret_cast<unsigned*>(&sAx[1][st][rb][l])[pq] = __builtin_bit_cast(unsigned, ll);
+    }
+    __syncthreads();     // (sG / sA are free again; the FIXG fill below is followed by another barrier)
+  } else {
+    for (int e = t; e < 32 * RB * 64; e += 256) {
+      const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
+      sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
+    }
   }
   // C and W hold N columns per row: the Gram elements [64 chunk0, 64 chunk0 + N) of the B*B (all of them when
   // chunk0 = 0 and N = B*B; a column slice in the member-sharded path)
@@ -1173,15 +1220,46 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[rb][cb][q] = 0.f;
+    if constexpr (X3) {
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const float af = sA[ks][rb][lane];
+      for (int st = 0; st < 4; ++st) {
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(&sSC[h][8 * st]), sc1 = *reinterpret_cast<const f32x4*>(&sSC[h][8 * st + 4]);
+        u32x4 bh[2], bl[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[S][ks][cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+          for (int pq = 0; pq < 4; ++pq) {
+            const float s0 = pq < 2 ? sc0[2 * pq] : sc1[2 * pq - 4], s1 = pq < 2 ? sc0[2 * pq + 1] : sc1[2 * pq - 3];
+            const f32x2 x = {bf[S][8 * st + 2 * pq][cb] * s0, bf[S][8 * st + 2 * pq + 1][cb] * s1};
+            const f16x2 hh = __builtin_convertvector(x, f16x2);
+            const f32x2 r = {x[0] - (float)hh[0], x[1] - (float)hh[1]};
+            const f16x2 ll = __builtin_convertvector(r, f16x2);
+            bh[cb][pq] = __builtin_bit_cast(unsigned, hh);
+            bl[cb][pq] = __builtin_bit_cast(unsigned, ll);
+          }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, sAx[0][st][rb][lane]), al = __builtin_bit_cast(f16x8, sAx[1][st][rb][lane]);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const f16x8 vh = __builtin_bit_cast(f16x8, bh[cb]), vl = __builtin_bit_cast(f16x8, bl[cb]);
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, vh, acc[rb][cb], 0, 0, 0);    // smallest products first
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vl, acc[rb][cb], 0, 0, 0);
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, vh, acc[rb][cb], 0, 0, 0);
+          }
+        }
       }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const float af = sA[ks][rb][lane];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[S][ks][cb], acc[rb][cb], 0, 0, 0);
+        }
+    }
     __builtin_amdgcn_wave_barrier();
     const int d0 = a - b0 - 2 * j;   // column offset of the Gram diagonal inside this lane's pair (0 or 1), if any
     const unsigned vW = 4u * h * rowN + (n0 + 2 * j) * 4u;
@@ -1195,7 +1273,8 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
         if constexpr (FIXG) gc = *reinterpret_cast<const f32x2*>(&sGC[ib + 4 * h][2 * j]);
         else gc = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsG, (int)vG, ib * B * 4, 0));
         const float gr = sG[wave][ib + 4 * h];
-        f32x2 w = {2.f * acc[rb][0][q] + gr - gc[0], 2.f * acc[rb][1][q] + gr - gc[1]};
+        const float two = X3 ? sRS[ib + 4 * h] : 2.f;
+        f32x2 w = {two * acc[rb][0][q] + gr - gc[0], two * acc[rb][1][q] + gr - gc[1]};
         if (detach_diag) {
           if (d0 == 0) w[0] = 0.f;
           if (d0 == 1) w[1] = 0.f;
@@ -2366,6 +2445,10 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   }
 }
 
+#ifndef HECKA_PW_SLOTS
+#define HECKA_PW_SLOTS 256
+#endif
+constexpr int kPairwiseSlots = HECKA_PW_SLOTS;
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -3287,15 +3370,21 @@ static int pairwise_self_batched_impl(const float* C_all, int L, int M, long lon
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, nsplit, n, S_all, 1.0f);
     return check_launch("pairwise_self_batched (reduce)");
   }
+  // The layers share the chip: kPairwiseSlots workgroups in ALL (two of these 512-thread workgroups fit a CU), not 256 per
+  // layer - a workgroup's fixed costs (first loads, the eight-wave reduction, its slab) are then spread over
+  // `spw` k-steps per wave instead of 4 at the bench shape, and the launch is one scheduling round.
   const long long nsteps = K / 32;
-  const int spw = (int)((nsteps + (long long)nsplit * 8 - 1) / ((long long)nsplit * 8));
+  int ns = nsplit;
+  if (ns > kPairwiseSlots / L) ns = kPairwiseSlots / L > 0 ? kPairwiseSlots / L : 1;
+  const int spw = (int)((nsteps + (long long)ns * 8 - 1) / ((long long)ns * 8));
+  ns = (int)((nsteps + (long long)spw * 8 - 1) / ((long long)spw * 8));
   if (pairwise_x6())
-    hipLaunchKernelGGL(pairwise_self64_kernel<true>, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws, rb);
+    hipLaunchKernelGGL(pairwise_self64_kernel<true>, dim3(ns, L), dim3(512), 0, st, C_all, K, spw, (float*)ws, rb);
   else
-    hipLaunchKernelGGL(pairwise_self64_kernel<false>, dim3(nsplit, L), dim3(512), 0, st, C_all, K, spw, (float*)ws, rb);
+    hipLaunchKernelGGL(pairwise_self64_kernel<false>, dim3(ns, L), dim3(512), 0, st, C_all, K, spw, (float*)ws, rb);
   if (int rc = check_launch("pairwise_self_batched")) return rc;
   const int n = M * M;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, nsplit, n, S_all, 1.0f);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 15) / 16, L), dim3(256), 0, st, (const float*)ws, ns, n, S_all, 1.0f);
   return check_launch("pairwise_self_batched (reduce)");
 }
 
@@ -3349,16 +3438,16 @@ static int combine_impl(const float* A, const float* C, const float* gamma, int 
     unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
     const bool fixg = combine_fixg(B, N, n_start, nwg);
     if (Ma == 64 && fixg)
-      hipLaunchKernelGGL((combine_stream_kernel<2, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+      hipLaunchKernelGGL((combine_stream_kernel<2, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, (const float*)nullptr, B, detach_diag, W, N,
                          n_start / 64, std_rows(64 * N), std_rows(64 * N));
     else if (Ma == 64)
-      hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+      hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg), dim3(256), 0, st, A, C, gamma, (const float*)nullptr, B, detach_diag, W, N,
                          n_start / 64, std_rows(64 * N), std_rows(64 * N));
     else if (fixg)
-      hipLaunchKernelGGL((combine_stream_kernel<1, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+      hipLaunchKernelGGL((combine_stream_kernel<1, true>), dim3(nwg), dim3(256), 0, st, A, C, gamma, (const float*)nullptr, B, detach_diag, W, N,
                          n_start / 64, std_rows(64 * N), std_rows(32 * N));
     else
-      hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, B, detach_diag, W, N,
+      hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg), dim3(256), 0, st, A, C, gamma, (const float*)nullptr, B, detach_diag, W, N,
                          n_start / 64, std_rows(64 * N), std_rows(32 * N));
     if (wm) {
       const int chunks = (int)(N >= (1 << 16) ? 16 : 1);
@@ -3401,9 +3490,9 @@ int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma,
 // blk_rows = 0: Cs_all [L][Mb][n], Ws_all [L][Ma][n].  blk_rows > 0 (Ma == Mb == 64, the streaming kernel only): the
 // exchange's layouts, Cs_all [Mb / blk_rows][Lin][blk_rows][n] of which the layers l0 .. l0 + L - 1 are processed,
 // Ws_all [Ma / blk_rows][L][blk_rows][n]; A_all / gamma_all hold the L processed layers.
-static int combine_slice_batched_impl(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Ma, int Mb,
-                                      int B, long long n_start, long long n_count, int detach_diag, float* Ws_all, int blk_rows,
-                                      int Lin, int l0, void* stream) {
+static int combine_slice_batched_impl(const float* A_all, const float* Cs_all, const float* gamma_all, const float* nsq_all,
+                                      int L, int Ma, int Mb, int B, long long n_start, long long n_count, int detach_diag,
+                                      float* Ws_all, int blk_rows, int Lin, int l0, void* stream) {
   clear_error();
   if (!A_all || !Cs_all || !gamma_all || !Ws_all) return fail(HECKA_EINVAL, "combine_slice_batched: null pointer%s");
   if (L <= 0 || L > 65535 || Ma <= 0 || Mb <= 0 || B <= 0 || n_start < 0 || n_count <= 0 || n_start + n_count > (long long)B * B)
@@ -3434,33 +3523,34 @@ static int combine_slice_batched_impl(const float* A_all, const float* Cs_all, c
   hipStream_t st = (hipStream_t)stream;
   unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
   const bool fixg = combine_fixg(B, N, n_start, nwg);
-  if (Ma == 64 && fixg)
-    hipLaunchKernelGGL((combine_stream_kernel<2, true>), dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag,
-                       Ws_all, N, n_start / 64, cb, wb);
-  else if (Ma == 64)
-    hipLaunchKernelGGL(combine_stream_kernel<2>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
-                       N, n_start / 64, cb, wb);
-  else if (fixg)
-    hipLaunchKernelGGL((combine_stream_kernel<1, true>), dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag,
-                       Ws_all, N, n_start / 64, cb, wb);
-  else
-    hipLaunchKernelGGL(combine_stream_kernel<1>, dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, B, detach_diag, Ws_all,
-                       N, n_start / 64, cb, wb);
+  const bool x3 = nsq_all != nullptr && config().combine_x3;      // (the caller passes nsq only in its f16x3 GEMM mode)
+#define HECKA_COMBINE_STREAM(RBK, FG, X) \
+  hipLaunchKernelGGL((combine_stream_kernel<RBK, FG, X>), dim3(nwg, L), dim3(256), 0, st, A_all, Cs_all, gamma_all, nsq_all, B, \
+                     detach_diag, Ws_all, N, n_start / 64, cb, wb)
+  if (Ma == 64) {
+    if (x3) { if (fixg) HECKA_COMBINE_STREAM(2, true, true); else HECKA_COMBINE_STREAM(2, false, true); }
+    else { if (fixg) HECKA_COMBINE_STREAM(2, true, false); else HECKA_COMBINE_STREAM(2, false, false); }
+  } else {
+    if (x3) { if (fixg) HECKA_COMBINE_STREAM(1, true, true); else HECKA_COMBINE_STREAM(1, false, true); }
+    else { if (fixg) HECKA_COMBINE_STREAM(1, true, false); else HECKA_COMBINE_STREAM(1, false, false); }
+  }
+#undef HECKA_COMBINE_STREAM
   return check_launch("combine_slice_batched");
 }
 
-int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Ma, int Mb,
-                                    int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
+int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, const float* nsq_all, int L,
+                                    int Ma, int Mb, int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
                                     void* stream) {
-  return combine_slice_batched_impl(A_all, Cs_all, gamma_all, L, Ma, Mb, B, n_start, n_count, detach_diag, Ws_all, 0, L, 0, stream);
+  return combine_slice_batched_impl(A_all, Cs_all, gamma_all, nsq_all, L, Ma, Mb, B, n_start, n_count, detach_diag, Ws_all, 0, L, 0,
+                                    stream);
 }
 
-int hecka_combine_slice_blocked_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Lin, int l0,
-                                    int Ma, int Mb, int B, long long n_start, long long n_count, int blk_rows,
+int hecka_combine_slice_blocked_f32(const float* A_all, const float* Cs_all, const float* gamma_all, const float* nsq_all, int L,
+                                    int Lin, int l0, int Ma, int Mb, int B, long long n_start, long long n_count, int blk_rows,
                                     int detach_diag, float* Ws_all, void* stream) {
   if (blk_rows <= 0) return fail(HECKA_EINVAL, "combine_slice_blocked: blk_rows must be positive%s");
-  return combine_slice_batched_impl(A_all, Cs_all, gamma_all, L, Ma, Mb, B, n_start, n_count, detach_diag, Ws_all, blk_rows, Lin,
-                                    l0, stream);
+  return combine_slice_batched_impl(A_all, Cs_all, gamma_all, nsq_all, L, Ma, Mb, B, n_start, n_count, detach_diag, Ws_all, blk_rows,
+                                    Lin, l0, stream);
 }
 
 int hecka_wbound_f32(const float* A, const float* nsq, const float* gamma, int Ma, int Mb, int B, float* wbound,

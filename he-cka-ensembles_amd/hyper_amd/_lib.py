@@ -71,7 +71,7 @@ SIGNATURES = {
     'hecka_conv_wgrad_x3_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     'hecka_conv_wgrad_x3_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp, _sz, _vp]),
     'hecka_combine_slice_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
-    'hecka_combine_slice_batched_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
+    'hecka_combine_slice_batched_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _vp, _vp]),
     'hecka_batchnorm_fwd_f32': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     'hecka_batchnorm_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp]),
     'hecka_gram_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
@@ -80,7 +80,7 @@ SIGNATURES = {
     'hecka_config_reload': (None, []),
     'hecka_blocked_rows_eligible': (_i, [_i, _ll, _i]),
     'hecka_pairwise_self_blocked_f32': (_i, [_vp, _i, _i, _ll, _i, _vp, _vp, _sz, _vp]),
-    'hecka_combine_slice_blocked_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp, _vp]),
+    'hecka_combine_slice_blocked_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp, _vp]),
 }
 
 

@@ -316,14 +316,24 @@ def combine_slice(A, Cs, gamma, B, n_start, detach_diag):
     return Ws
 
 
-def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag):
-    """combine_slice for all layers in one launch: A_all [L,Ma,Mb], Cs_all [L,Mb,n], gamma_all [L,Ma,B] -> Ws_all [L,Ma,n]."""
+def _nsq_arg(nsq_all, Ln, Mb):
+    """nsq [L, Mb] for the fp16-split combine (include/hecka.h) - only in the f16x3 GEMM mode; None otherwise."""
+    if nsq_all is None or get_gemm_mode() != 0:
+        return None
+    assert nsq_all.shape == (Ln, Mb) and nsq_all.is_contiguous() and nsq_all.dtype == torch.float32
+    return _p(nsq_all)
+
+
+def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag, nsq_all=None):
+    """combine_slice for all layers in one launch: A_all [L,Ma,Mb], Cs_all [L,Mb,n], gamma_all [L,Ma,B] -> Ws_all [L,Ma,n].
+    nsq_all [L,Mb] = ||C_j||_F^2 of the members' WHOLE Grams (the pairwise diagonal): products on the fp16 matrix cores."""
     Ln, Ma, Mb = A_all.shape
     n = Cs_all.shape[2]
     Ws = torch.empty((Ln, Ma, n), device=Cs_all.device, dtype=torch.float32)
     if n:
-        _lib.check(_lib.lib().hecka_combine_slice_batched_f32(_p(A_all), _p(Cs_all), _p(gamma_all), Ln, Ma, Mb, B, n_start, n,
-                                                              int(bool(detach_diag)), _p(Ws), _stream()), 'combine_slice_batched')
+        _lib.check(_lib.lib().hecka_combine_slice_batched_f32(_p(A_all), _p(Cs_all), _p(gamma_all), _nsq_arg(nsq_all, Ln, Mb), Ln,
+                                                              Ma, Mb, B, n_start, n, int(bool(detach_diag)), _p(Ws), _stream()),
+                   'combine_slice_batched')
     return Ws
 
 
@@ -494,14 +504,15 @@ def pairwise_self_blocked(Cbuf):
     return S_all
 
 
-def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag):
+def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag, nsq_part=None):
     """Layers l0 .. l0 + Lc - 1 of Cbuf [G, Lin, Ml, n] combined with A_part [Lc, 64, 64] / gamma_part [Lc, 64, B] into
     Ws [G, Lc, Ml, n] - the send order of the returning exchange for that group of layers."""
     G, Lin, Ml, n = Cbuf.shape
     Lc, Ma, Mb = A_part.shape
     Ws = torch.empty((G, Lc, Ml, n), device=Cbuf.device, dtype=torch.float32)
-    _lib.check(_lib.lib().hecka_combine_slice_blocked_f32(_p(A_part), _p(Cbuf), _p(gamma_part), Lc, Lin, int(l0), Ma, Mb, B,
-                                                          n_start, n, Ml, int(bool(detach_diag)), _p(Ws), _stream()),
+    _lib.check(_lib.lib().hecka_combine_slice_blocked_f32(_p(A_part), _p(Cbuf), _p(gamma_part), _nsq_arg(nsq_part, Lc, Mb), Lc, Lin,
+                                                          int(l0), Ma, Mb, B, n_start, n, Ml, int(bool(detach_diag)), _p(Ws),
+                                                          _stream()),
                'combine_slice_blocked')
     return Ws
 
@@ -588,7 +599,7 @@ class DiversityLayers(torch.autograd.Function):
         wmaxs = [wmax_all[li] for li in range(Ln)]
         if gram_bwd_multi_eligible(Cs, Xs, wmaxs, xmaxs):      # every W in ONE combine launch, then ONE dX launch
             M, B = Xs[0].shape[0], Xs[0].shape[1]
-            W_all = combine_slice_batched(A_all, _stacked(Cs).view(Ln, M, B * B), gamma_all, B, 0, detach_diag)
+            W_all = combine_slice_batched(A_all, _stacked(Cs).view(Ln, M, B * B), gamma_all, B, 0, detach_diag, nsq_all)
             return (None,) + tuple(gram_bwd_multi([W_all[li] for li in range(Ln)], Xs, wmaxs, xmaxs, ctx.gate))
         grads = []
         for li in range(Ln):

@@ -355,7 +355,8 @@ class _SlicedLayers(torch.autograd.Function):
             pend = []
             for part in parts:
                 l0, Lc = part[0], len(part)
-                Ws = be.combine_slice_blocked(A_all[l0:l0 + Lc], Cs_all, gamma_all[l0:l0 + Lc], l0, B, bounds[rank], detach)
+                Ws = be.combine_slice_blocked(A_all[l0:l0 + Lc], Cs_all, gamma_all[l0:l0 + Lc], l0, B, bounds[rank], detach,
+                                              nsq_all[l0:l0 + Lc])
                 Wr = torch.empty((world, Lc, Ml, ctx.sliced, B), device=Ws.device, dtype=Ws.dtype)
                 pend.append((part, Wr, _a2a_equal(Wr.view(-1), Ws.view(-1), group)))
             for part, Wr, work in pend:
@@ -371,7 +372,7 @@ class _SlicedLayers(torch.autograd.Function):
         if not n_r:
             Ws_all = torch.empty((L, M, 0), device=Cs_all.device, dtype=Cs_all.dtype)
         elif hasattr(be, 'combine_slice_batched'):
-            Ws_all = be.combine_slice_batched(A_all, Cs_all, gamma_all, B, bounds[rank], detach)        # [L, M, n_r]
+            Ws_all = be.combine_slice_batched(A_all, Cs_all, gamma_all, B, bounds[rank], detach, nsq_all)        # [L, M, n_r]
         else:
             Ws_all = torch.stack([be.combine_slice(A_all[li], Cs_all[li], gamma_all[li], B, bounds[rank], detach) for li in range(L)])
         recv = {}

@@ -175,8 +175,8 @@ int hecka_pairwise_self_batched_f32(const float* C_all, int L, int M, long long 
 int hecka_blocked_rows_eligible(int M, long long n, int blk_rows);
 int hecka_pairwise_self_blocked_f32(const float* C_all, int L, int M, long long K, int blk_rows, float* S_all, void* ws,
                                     size_t ws_bytes, void* stream);
-int hecka_combine_slice_blocked_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Lin, int l0,
-                                    int Ma, int Mb, int B, long long n_start, long long n_count, int blk_rows,
+int hecka_combine_slice_blocked_f32(const float* A_all, const float* Cs_all, const float* gamma_all, const float* nsq_all, int L,
+                                    int Lin, int l0, int Ma, int Mb, int B, long long n_start, long long n_count, int blk_rows,
                                     int detach_diag, float* Ws_all, void* stream);
 int hecka_wbound_batched_f32(const float* A, const float* nsq, const float* gamma, int L, int Ma, int Mb, int B,
                              float* wbound, void* stream);
@@ -190,9 +190,15 @@ int hecka_combine_slice_f32(const float* A, const float* Cs, const float* gamma,
                             long long n_start, long long n_count, int detach_diag, float* Ws, void* stream);
 /* hecka_combine_slice_f32 for L layers in one launch: A_all [L,Ma,Mb], Cs_all [L,Mb,n_count], gamma_all [L,Ma,B],
  * Ws_all [L,Ma,n_count], all contiguous, the same slice [n_start, n_start + n_count) of every layer (a member shard's
- * slice is 1/G of a Gram: one layer alone is a launch-bound 17 MB). */
-int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, int L, int Ma, int Mb,
-                                    int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
+ * slice is 1/G of a Gram: one layer alone is a launch-bound 17 MB).
+ * nsq_all [L,Mb] (may be NULL): nsq[j] = ||C_j||_F^2 of the WHOLE Gram of member j, the diagonal of hecka_pairwise_*'s S.
+ * Given (and Mb == 64, Ma in {32, 64}, whole 64-column chunks), the 64-deep products run on the fp16 matrix cores as
+ * three products of two-term fp16 splits (the arithmetic of the Gram and dX GEMMs; error <= 2^-21 of sum_j |A_ij C_j[n]|),
+ * with exact power-of-two scales per member taken from sqrt(nsq[j]) >= max |C_j| - which moves the stage from the
+ * fp32-MFMA floor to the HBM side.  NULL (or HECKA_COMBINE_X3=0): fp32 MFMA products.  Same argument in
+ * hecka_combine_slice_blocked_f32. */
+int hecka_combine_slice_batched_f32(const float* A_all, const float* Cs_all, const float* gamma_all, const float* nsq_all, int L,
+                                    int Ma, int Mb, int B, long long n_start, long long n_count, int detach_diag, float* Ws_all,
                                     void* stream);
 
 /* Upper bound of max |W_i| from what already exists: wbound[i] = 2 sum_j |A[i,j]| sqrt(nsq[j]) + 2 max_b |gamma[i,b]|

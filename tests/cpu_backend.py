@@ -146,7 +146,7 @@ def coef_gamma_batched(A_all, cv_all):
     return torch.stack([coef_gamma(A, c) for A, c in zip(A_all, cv_all)])
 
 
-def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag):
+def combine_slice_batched(A_all, Cs_all, gamma_all, B, n_start, detach_diag, nsq_all=None):
     CALLS['combine_batched'] = CALLS.get('combine_batched', 0) + 1
     return torch.stack([combine_slice(A, Cs, g, B, n_start, detach_diag) for A, Cs, g in zip(A_all, Cs_all, gamma_all)])
 
@@ -169,7 +169,7 @@ def pairwise_self_blocked(Cbuf):
     return pairwise_self_batched(Cbuf.permute(1, 0, 2, 3).reshape(L, G * Ml, n))
 
 
-def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag):
+def combine_slice_blocked(A_part, Cbuf, gamma_part, l0, B, n_start, detach_diag, nsq_part=None):
     G, Lin, Ml, n = Cbuf.shape
     Lc = A_part.shape[0]
     CALLS['combine_blocked'] = CALLS.get('combine_blocked', 0) + 1

@@ -127,6 +127,41 @@ def test_batched_combine_slice_equals_per_layer(M, Ml, B, world):
         assert torch.equal(Wb[l], ops.combine_slice(A[l], Cs[l], gamma[l], B, s, True)), l
 
 
+@pytest.mark.parametrize('Ma,B,n_start,n', [(64, 256, 0, 256 * 256), (64, 128, 128 * 32, 128 * 64), (32, 128, 0, 128 * 128),
+                                            (64, 192, 64 * 7, 64 * 50)])
+def test_fp16_split_combine_matches_fp64_with_members_decades_apart(Ma, B, n_start, n):
+    """hecka_combine_slice_batched_f32 with nsq (three fp16 products, per-member power-of-two scales from sqrt(nsq_j),
+    per-row scales of the folded A) against fp64 and against the fp32-MFMA form: members' Grams six decades apart with
+    coefficients A_ij ~ 1 / (|C_i| |C_j|) as the normalised heads produce them, so every member contributes equally to a
+    row of W; whole-Gram, slice (both kernel forms: fixed strip / general chunks) and the 32-row variant."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(B + Ma)
+    L, M = 2, 64
+    spread = 10.0 ** torch.linspace(-3, 3, M, device=dev)
+    Cfull = torch.randn(L, M, B * B, device=dev) * spread[None, :, None] * torch.tensor([1.0, 40.0], device=dev)[:, None, None]
+    Cfull[1, 5] = 0                                                  # a member with an all-zero Gram
+    nrm = Cfull.norm(dim=2).clamp_min(1e-30)
+    A = (torch.randn(L, M, M, device=dev) / (nrm[:, :, None] * nrm[:, None, :]))[:, :Ma].contiguous()
+    A[0, 3] = 0                                                      # an all-zero row of A
+    A[1, :, 5] = 0                                                   # (and no coefficient on the zero Gram)
+    nsq = Cfull.double().square().sum(dim=2).float()
+    Cs = Cfull[:, :, n_start:n_start + n].contiguous()
+    gamma = torch.randn(L, Ma, B, device=dev) * 1e-2 * (A.abs().amax(dim=2) * Cs.abs().amax(dim=2).amax(dim=1, keepdim=True))[:, :, None]
+    W3 = ops.combine_slice_batched(A, Cs, gamma, B, n_start, True, nsq)
+    W1 = ops.combine_slice_batched(A, Cs, gamma, B, n_start, True)
+    a = torch.arange(n_start, n_start + n, device=dev) // B
+    b = torch.arange(n_start, n_start + n, device=dev) % B
+    Wd = 2.0 * (A.double() @ Cs.double()) + gamma.double()[:, :, a] - gamma.double()[:, :, b]
+    Wd[:, :, a == b] = 0
+    scale = Wd.abs().amax(dim=2).clamp_min(1e-300)
+    e3 = float(((W3.double() - Wd).abs().amax(dim=2) / scale).max())
+    e1 = float(((W1.double() - Wd).abs().amax(dim=2) / scale).max())
+    assert torch.isfinite(W3).all()
+    assert e3 <= 1e-6 and e1 <= 1e-6, (e3, e1)
+    assert bool((W3[0, 3] == (gamma[0, 3][a] - gamma[0, 3][b]) * (a != b)).all())       # zero row of A: the gamma terms alone
+
+
 @pytest.mark.parametrize('Ml,B,rows', [(8, 512, 64), (16, 256, 64), (32, 128, 64), (64, 128, 128)])
 def test_blocked_layouts_are_bit_equal_to_the_standard_ones(Ml, B, rows):
     """The layouts of the one-all_to_all-per-exchange path (64 members in blocks of Ml rows, all layers in one buffer):
@@ -143,11 +178,14 @@ def test_blocked_layouts_are_bit_equal_to_the_standard_ones(Ml, B, rows):
     A = torch.randn(L, M, M, device=dev) / M
     gamma = torch.randn(L, M, B, device=dev)
     n_start = n * (1 if B * B >= 2 * n else 0)
-    Wstd = ops.combine_slice_batched(A, Cstd, gamma, B, n_start, True)
-    for l0, Lc in ((0, 1), (1, 2), (0, 3)):
-        Wb = ops.combine_slice_blocked(A[l0:l0 + Lc].contiguous(), Cblk, gamma[l0:l0 + Lc].contiguous(), l0, B, n_start, True)
-        assert Wb.shape == (G, Lc, Ml, n)
-        assert torch.equal(Wb.permute(1, 0, 2, 3).reshape(Lc, M, n), Wstd[l0:l0 + Lc]), (l0, Lc)
+    nsq = 1.5 * Cstd.square().sum(dim=2)           # (a slice's norm is below the whole Gram's)
+    for nq in (None, nsq):                         # fp32-MFMA products / the fp16-split ones
+        Wstd = ops.combine_slice_batched(A, Cstd, gamma, B, n_start, True, nq)
+        for l0, Lc in ((0, 1), (1, 2), (0, 3)):
+            Wb = ops.combine_slice_blocked(A[l0:l0 + Lc].contiguous(), Cblk, gamma[l0:l0 + Lc].contiguous(), l0, B, n_start, True,
+                                           None if nq is None else nq[l0:l0 + Lc])
+            assert Wb.shape == (G, Lc, Ml, n)
+            assert torch.equal(Wb.permute(1, 0, 2, 3).reshape(Lc, M, n), Wstd[l0:l0 + Lc]), (l0, Lc)
     # Gram / dX with every layer in one buffer (a rank's Ml members)
     # (8 members x 512 samples with deep layers: the launch splits them over K - slabs, then the placing reduction)
     Ps = (4096, 2048, 256) if Ml == 8 else ((512, 256, 128) if B % 256 == 0 else (256, 128, 128))

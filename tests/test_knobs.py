@@ -29,7 +29,8 @@ def test_config_is_read_once_and_reloaded_on_request(monkeypatch):
     import subprocess
     import sys
     code = ("import sys; sys.path[:0] = %r; import os; os.environ['HECKA_SHARD_EXCHANGE'] = 'bogus'\n"
-            "try:\n    import hyper_amd.config\nexcept ValueError as e:\n    print('refused:', e)" % (sys.path[:3],))
+            "try:\n    import hyper_amd.config\nexcept ValueError as e:\n    print('refused:', e)" %
+            ([os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'he-cka-ensembles_amd')],))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert 'refused' in out.stdout, out.stdout + out.stderr
 
@@ -51,6 +52,7 @@ def _loss_and_grads(M, B, Ps, seed=3, kernel='linear'):
 @pytest.mark.parametrize('knob,value,shape,tol', [
     ('HECKA_COMBINE_FIXG', '0', (64, 256, (512, 256)), 0.0),        # column terms re-loaded per chunk: same sums, bit-equal
     ('HECKA_COLMEAN_MULTI', '0', (64, 256, (512, 256)), 0.0),       # one column-mean launch per layer: bit-equal
+    ('HECKA_COMBINE_X3', '0', (64, 256, (512, 256)), 2e-6),         # all-layers combine on fp32 MFMAs instead of fp16 splits
     ('HECKA_BWD_TN', '128', (64, 256, (512, 256)), 2e-6),           # four-wave 256 x 128 dX tiles: another summation order
     ('HECKA_PAIRWISE_X6', '1', (64, 256, (512, 256)), 5e-6),        # bf16 six-product pairwise: inside the parity budget
     ('HECKA_SMALL_GRID', '1', (5, 300, (864, 256)), 1e-5),          # ragged small grid forced onto 128-row fp32-MFMA tiles
