@@ -1141,52 +1141,10 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
   C += (size_t)blockIdx.y * cb.lay;
   gamma += (size_t)blockIdx.y * (32 * RB) * B;
   W += (size_t)blockIdx.y * wb.lay;
-  if constexpr (X3) {
-    float* sAf = &sA[0][0][0];           // A'[i][j] = A_ij / sc_j, 64 floats per row
-    float* sRA = &sG[0][0];              // ra_i (sG is not used before the chunk loop)
-    nsq += (size_t)blockIdx.y * 64;
-    if (t < 64) sSC[t & 1][t >> 1] = pow2_scale(sqrtf(fmaxf(nsq[t], 0.f)), 14);
-    __syncthreads();
-    for (int e = t; e < 32 * RB * 64; e += 256) sAf[e] = A[e] * (1.0f / sSC[e & 1][(e & 63) >> 1]);
-    __syncthreads();
-    if (t < 32 * RB) {
-      float mx = 0.f;
-      for (int q = 0; q < 64; ++q) mx = fmaxf(mx, fabsf(sAf[t * 64 + ((q + t) & 63)]));
-      // (pow2_scale's exponent range of +-60 is meant for products of two scales; a row of A may lie further out)
-      const int be = (int)((__float_as_uint(mx) >> 23) & 0xFF);
-      int k = (be == 0 || be == 255) ? 0 : 14 - (be - 126);
-      k = k < -120 ? -120 : (k > 120 ? 120 : k);
-      sRA[t] = __uint_as_float((unsigned)(127 + k) << 23);
-      sRS[t] = __uint_as_float((unsigned)(128 - k) << 23);      // 2 / ra
-    }
-    __syncthreads();
-    for (int idx = t; idx < 4 * RB * 64 * 4; idx += 256) {
-      const int pq = idx & 3, l = (idx >> 2) & 63, rb = (idx >> 8) % RB, st = idx / (256 * RB);
-      const int i = rb * 32 + (l & 31), j0 = 16 * st + 4 * pq + (l >> 5);
-      const float ra = sRA[i];
-      const f32x2 x = {sAf[i * 64 + j0] * ra, sAf[i * 64 + j0 + 2] * ra};
-      const f16x2 hh = __builtin_convertvector(x, f16x2);
-      const f32x2 r = {x[0] - (float)hh[0], x[1] - (float)hh[1]};
-      const f16x2 ll = __builtin_convertvector(r, f16x2);
-      reinterpret_cast<unsigned*>(&sAx[0][st][rb][l])[pq] = __builtin_bit_cast(unsigned, hh);
-      reinterpret_cast<unsigned*>(&sAx[1][st][rb][l])[pq] = __builtin_bit_cast(unsigned, ll);
-    }
-    __syncthreads();     // (sG / sA are free again; the FIXG fill below is followed by another barrier)
-  } else {
-    for (int e = t; e < 32 * RB * 64; e += 256) {
-      const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
-      sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
-    }
-  }
   // C and W hold N columns per row: the Gram elements [64 chunk0, 64 chunk0 + N) of the B*B (all of them when
   // chunk0 = 0 and N = B*B; a column slice in the member-sharded path)
   const int strips = B / 64;
   const long long nchunks = N / 64;
-  if constexpr (FIXG) {
-    const int b0s = (int)(blockIdx.x % strips) * 64;
-    for (int e = t; e < 32 * RB * 64; e += 256) sGC[e >> 6][e & 63] = gamma[(size_t)(e >> 6) * B + b0s + (e & 63)];
-  }
-  __syncthreads();
   // buffer addressing: one per-lane byte offset per chunk + scalar row offsets (no 64-bit pointers kept per row)
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C), 0, (int)(cb.row_bytes(63, N) + (unsigned)N * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(W, 0, (int)(wb.row_bytes(32 * RB - 1, N) + (unsigned)N * 4u), 0x00020000);
@@ -1283,7 +1241,52 @@ __global__ __launch_bounds__(256, 2) void combine_stream_kernel(const float* __r
       }
     __builtin_amdgcn_wave_barrier();
   };
-  if (c < nchunks) load_b(std::integral_constant<int, 0>{}, c);
+  if (c < nchunks) load_b(std::integral_constant<int, 0>{}, c);     // the first chunk's lines travel during the set-up
+  auto setup = [&]() __attribute__((always_inline)) {
+    if constexpr (X3) {
+      float* sAf = &sA[0][0][0];           // A'[i][j] = A_ij / sc_j, 64 floats per row
+      float* sRA = &sG[0][0];              // ra_i (sG is not used before the chunk loop)
+      nsq += (size_t)blockIdx.y * 64;
+      if (t < 64) sSC[t & 1][t >> 1] = pow2_scale(sqrtf(fmaxf(nsq[t], 0.f)), 14);
+      __syncthreads();
+      for (int e = t; e < 32 * RB * 64; e += 256) sAf[e] = A[e] * (1.0f / sSC[e & 1][(e & 63) >> 1]);
+      __syncthreads();
+      if (t < 32 * RB) {
+        float mx = 0.f;
+        for (int q = 0; q < 64; ++q) mx = fmaxf(mx, fabsf(sAf[t * 64 + ((q + t) & 63)]));
+        // (pow2_scale's exponent range of +-60 is meant for products of two scales; a row of A may lie further out)
+        const int be = (int)((__float_as_uint(mx) >> 23) & 0xFF);
+        int k = (be == 0 || be == 255) ? 0 : 14 - (be - 126);
+        k = k < -120 ? -120 : (k > 120 ? 120 : k);
+        sRA[t] = __uint_as_float((unsigned)(127 + k) << 23);
+        sRS[t] = __uint_as_float((unsigned)(128 - k) << 23);      // 2 / ra
+      }
+      __syncthreads();
+      for (int idx = t; idx < 4 * RB * 64 * 4; idx += 256) {
+        const int pq = idx & 3, l = (idx >> 2) & 63, rb = (idx >> 8) % RB, st = idx / (256 * RB);
+        const int i = rb * 32 + (l & 31), j0 = 16 * st + 4 * pq + (l >> 5);
+        const float ra = sRA[i];
+        const f32x2 x = {sAf[i * 64 + j0] * ra, sAf[i * 64 + j0 + 2] * ra};
+        const f16x2 hh = __builtin_convertvector(x, f16x2);
+        const f32x2 r = {x[0] - (float)hh[0], x[1] - (float)hh[1]};
+        const f16x2 ll = __builtin_convertvector(r, f16x2);
+        reinterpret_cast<unsigned*>(&sAx[0][st][rb][l])[pq] = __builtin_bit_cast(unsigned, hh);
+        reinterpret_cast<unsigned*>(&sAx[1][st][rb][l])[pq] = __builtin_bit_cast(unsigned, ll);
+      }
+      __syncthreads();     // (sG / sA are free again; the FIXG fill below is followed by another barrier)
+    } else {
+      for (int e = t; e < 32 * RB * 64; e += 256) {
+        const int l = e & 63, rb = (e >> 6) % RB, ks = e / (64 * RB);
+        sA[ks][rb][l] = A[(size_t)(rb * 32 + (l & 31)) * 64 + 2 * ks + (l >> 5)];
+      }
+    }
+    if constexpr (FIXG) {
+      const int b0s = (int)(blockIdx.x % strips) * 64;
+      for (int e = t; e < 32 * RB * 64; e += 256) sGC[e >> 6][e & 63] = gamma[(size_t)(e >> 6) * B + b0s + (e & 63)];
+    }
+    __syncthreads();
+  };
+  setup();
   while (c < nchunks) {
     chunk(std::integral_constant<int, 0>{}, c);
     c += cstep;
@@ -2449,6 +2452,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
 #define HECKA_PW_SLOTS 256
 #endif
 constexpr int kPairwiseSlots = HECKA_PW_SLOTS;
+constexpr int kCombineSlots = 512;
 static int pairwise_nsplit(int Ma, int Mb, long long K) {
   const long long tiles = (long long)((Ma + 63) / 64) * ((Mb + 63) / 64);
   const long long ktiles = (K + kBK - 1) / kBK;
@@ -3521,7 +3525,9 @@ static int combine_slice_batched_impl(const float* A_all, const float* Cs_all, c
     return HECKA_OK;
   }
   hipStream_t st = (hipStream_t)stream;
-  unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, 512));
+  // The layers share the chip: kCombineSlots workgroups in ALL (two per CU), so that a workgroup's set-up - A into LDS (split
+  // into fp16 planes in the X3 form), its strip's column terms - is spread over more than two chunks per wave.
+  unsigned nwg = (unsigned)std::max<long long>(1, std::min<long long>(N / 256, std::max(kCombineSlots / L, B / 64)));
   const bool fixg = combine_fixg(B, N, n_start, nwg);
   const bool x3 = nsq_all != nullptr && config().combine_x3;      // (the caller passes nsq only in its f16x3 GEMM mode)
 #define HECKA_COMBINE_STREAM(RBK, FG, X) \

@@ -30,6 +30,14 @@ def timed(fn, n=12, warm=3):
 
 out = ops.centered_gram_multi(Xs)
 xmaxs = [o[2] for o in out]
+# (accuracy of the Gram against fp64 on the narrowest and the deepest layer, so that a variant build is not timed blind)
+errs = []
+for li in (0, len(DIMS) - 1):
+    Xd = Xs[li][:4].double()
+    Kd = Xd @ Xd.transpose(1, 2)
+    Cd = Kd - Kd.mean(dim=2, keepdim=True)
+    errs.append(float((out[li][0][:4].double() - Cd).abs().max() / Cd.abs().max()))
 tg = timed(lambda: ops.centered_gram_multi(Xs))          # (includes the column-mean launch)
 tb = timed(lambda: ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs))
-print('%-10s colmean+gram %8.1f us   dX %8.1f us' % (sys.argv[1] if len(sys.argv) > 1 else '', tg, tb), flush=True)
+print('%-10s colmean+gram %8.1f us   dX %8.1f us   gram err %.1e / %.1e' % (sys.argv[1] if len(sys.argv) > 1 else '', tg, tb, errs[0], errs[1]),
+      flush=True)
