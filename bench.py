@@ -317,9 +317,9 @@ def main():
         else:
             kname, peak, hw = 'gram_bwd_kernel (dX = W X, fp32 MFMA)', PEAK_F32_MATRIX_TFLOPS, {}
         # HBM bytes per launch of the dominant kernel: not measurable from inside a run - taken from the committed
-        # rocprofv3 PMC passes of this same command (profiles/r02_hbm_traffic.json says how), single-GPU f16x3 only
+        # rocprofv3 PMC passes of this same command (profiles/r03_hbm_traffic.json says how), single-GPU f16x3 only
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r03_hbm_traffic.json')
         if world == 1 and mode == 0 and os.path.exists(tfile):
             with open(tfile) as fh:
                 tk = json.load(fh)['kernels']
