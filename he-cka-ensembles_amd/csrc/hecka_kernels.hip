@@ -3034,9 +3034,97 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
 // Split-K plan of a multi-layer Gram launch: none while the unsplit grid already fills the GPU twice over (1024
 // workgroups); otherwise every layer is cut into pieces of about d* features, d* = total depth / 1024 (at least 1024),
 // at most 8 per layer.  Returns the workspace bytes (0: no split).
+static GramPairTiles gram_pair_tiles(int n);
+
+// The same for the paired 128 x 256 tiles (one 512-thread workgroup per CU: 256 slots).  The launch hands its workgroups
+// out in grid order - deepest layer first, a layer's pieces together - each to the CU that frees up first, so the plan
+// is found by running that hand-out on the host (a group of equal pieces at a time) for a few candidate piece depths d (P_l / k of every layer; a
+// layer is cut into round(P_l / d) <= 8 pieces of whole 32-k tiles) and taking the shortest finish, counting
+// 128 features' worth of fixed cost per workgroup and, for split layers, the slabs' write + read in the reduction
+// (0.052 us per feature of depth on this tile, slabs at 4 TB/s).  8 members, five layers of 512 .. 8192: (3, 2, 1, 1, 1)
+// - 141 us of makespan where the square tiles' rule (7, 3, 2, 1, 1) gave 165 us + twice the slab traffic.
+static double gram_pair_finish(int L, long long per, const int* P, const int* ns, const int* kc, double slab_feat) {
+  double ft[256];      // when each CU frees up, kept sorted; a group of equal pieces goes to the earliest ones in turn
+  for (int i = 0; i < 256; ++i) ft[i] = 0.0;
+  double slabs = 0.0;
+  for (int l = 0; l < L; ++l) {
+    for (int z = 0; z < ns[l]; ++z) {
+      const double depth = (double)std::min<long long>(kc[l], P[l] - (long long)z * kc[l]) + 128.0;
+      for (long long left = per; left > 0; left -= 256) {
+        const int n = (int)std::min<long long>(left, 256);
+        for (int i = 0; i < n; ++i) ft[i] += depth;
+        std::sort(ft, ft + 256);
+      }
+    }
+    if (ns[l] > 1) slabs += ns[l];
+  }
+  return ft[255] + slabs * slab_feat + (slabs > 0 ? 100.0 : 0.0);
+}
+
+static size_t gram_pair_split_plan(int L, int M, int B, const int* P, int ntile, int* nsplit, int* kchunk) {
+  struct Plan { int L, M, B, P[kMaxGramLayers], ns[kMaxGramLayers], kc[kMaxGramLayers]; };
+  static thread_local Plan cache[8] = {};
+  static thread_local int next = 0;
+  const Plan* plan = nullptr;
+  for (int c = 0; c < 8 && !plan; ++c) {
+    bool hit = cache[c].L == L && cache[c].M == M && cache[c].B == B;
+    for (int i = 0; i < L && hit; ++i) hit = cache[c].P[i] == P[i];
+    if (hit) plan = &cache[c];
+  }
+  if (!plan) {
+    const long long per = (long long)M * gram_pair_tiles(ntile).n;
+    const double slab_feat = 2.0 * (double)M * B * B * 4.0 / 4.0e6 / 0.052;
+    Plan pl = {};
+    pl.L = L; pl.M = M; pl.B = B;
+    for (int i = 0; i < L; ++i) { pl.P[i] = P[i]; pl.ns[i] = 1; pl.kc[i] = P[i]; }
+    if (per * L < 1024 && !config().gram_nosplit) {
+      double best = gram_pair_finish(L, per, P, pl.ns, pl.kc, slab_feat);
+      unsigned long long seen[64];
+      int nseen = 0;
+      int ns[kMaxGramLayers], kc[kMaxGramLayers];
+      for (int l = 0; l < L; ++l)
+        for (int k = 2; k <= 8; ++k) {
+          const double d = (double)P[l] / k;
+          if (d < 256.0) break;
+          unsigned long long sig = 0;
+          for (int i = 0; i < L; ++i) {
+            const long long n = std::min<long long>(8, std::max<long long>(1, (long long)((double)P[i] / d + 0.5)));
+            const long long c = ((P[i] / 32 + n - 1) / n) * 32;
+            kc[i] = (int)c;
+            ns[i] = (int)((P[i] + c - 1) / c);
+            sig = sig * 9 + (unsigned long long)ns[i];
+          }
+          bool dup = false;
+          for (int q = 0; q < nseen && !dup; ++q) dup = seen[q] == sig;
+          if (dup || nseen == 64) continue;
+          seen[nseen++] = sig;
+          const double f = gram_pair_finish(L, per, P, ns, kc, slab_feat);
+          if (f < best * 0.97) {        // (a split must pay for itself with some margin)
+            best = f;
+            for (int i = 0; i < L; ++i) { pl.ns[i] = ns[i]; pl.kc[i] = kc[i]; }
+          }
+        }
+    }
+    cache[next] = pl;
+    plan = &cache[next];
+    next = (next + 1) & 7;
+  }
+  size_t bytes = 0;
+  for (int i = 0; i < L; ++i) {
+    nsplit[i] = plan->ns[i];
+    kchunk[i] = plan->kc[i];
+    if (nsplit[i] > 1) bytes += (size_t)nsplit[i] * ((size_t)M * B * B + (size_t)M * B) * sizeof(float);
+  }
+  return bytes;
+}
+
 static size_t gram_split_plan(int L, int M, int B, const int* P, int* nsplit, int* kchunk) {
   const int ntile = (B + 127) / 128;
   const long long per = (long long)M * (ntile * (ntile + 1) / 2);
+  // (the shapes the paired tiles take - whatever else the launch then decides, a plan made for them is valid for any kernel)
+  bool pair_shape = config().gram_pair && config().k32 && B % 128 == 0 && ntile >= 2 && ntile <= 8 && L <= kMaxGramLayers;
+  for (int i = 0; i < L && pair_shape; ++i) pair_shape = P[i] % 32 == 0;
+  if (pair_shape) return gram_pair_split_plan(L, M, B, P, ntile, nsplit, kchunk);
   long long work = 0;
   for (int i = 0; i < L; ++i) {
     work += per * P[i];
