@@ -2316,6 +2316,37 @@ __device__ __forceinline__ BnMap bn_map(long long S) {
   return m;
 }
 
+// One sweep of a thread over its float4s of the (group, channel) slab: load(offset) -> value, use(offset, value).  A
+// slab of the first ResNet stage is 512 KB for ONE workgroup and the grid (channels x members) is 2.5 workgroups per CU:
+// with one float4 in flight per thread the sweeps ran at 3.4 TB/s.  When a thread owns one float4 per image (S / 4 a power
+// of two <= 256: every shipped shape) four images' loads are issued before the first is used.
+template <class Load, class Use>
+__device__ __forceinline__ void bn_sweep(const BnMap& m, int N, size_t base, size_t nstride, Load&& load, Use&& use) {
+  if (m.s4 == m.tpi) {
+    const size_t o0 = base + 4 * (size_t)m.si, step = (size_t)m.ipp * nstride;
+    int n = m.ni;
+    size_t o = o0 + (size_t)n * nstride;
+    for (; n + 3 * m.ipp < N; n += 4 * m.ipp, o += 4 * step) {
+      auto v0 = load(o);
+      auto v1 = load(o + step);
+      auto v2 = load(o + 2 * step);
+      auto v3 = load(o + 3 * step);
+      use(o, v0);
+      use(o + step, v1);
+      use(o + 2 * step, v2);
+      use(o + 3 * step, v3);
+    }
+    for (; n < N; n += m.ipp, o += step) use(o, load(o));
+    return;
+  }
+  for (int n = m.ni; n < N; n += m.ipp) {
+    const size_t o = base + (size_t)n * nstride;
+    for (int q = m.si; q < m.s4; q += m.tpi) use(o + 4 * (size_t)q, load(o + 4 * (size_t)q));
+  }
+}
+struct BnPair { f32x4 d, v; };
+struct BnTriple { f32x4 d, v, y; };
+
 __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __restrict__ x, int N, int C, long long S,
                                                                 const float* __restrict__ weight, const float* __restrict__ bias,
                                                                 const float* __restrict__ run_mean, const float* __restrict__ run_var,
@@ -2335,15 +2366,12 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
   if (training) {
     const float K = x[base];
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-    for (int n = m.ni; n < N; n += m.ipp) {
-      const float* xp = x + base + (size_t)n * nstride;
-      for (int q = m.si; q < m.s4; q += m.tpi) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(xp + 4 * q);
-        v -= K;
-        a1 += v;
-        a2 += v * v;
-      }
-    }
+    bn_sweep(m, N, base, nstride, [&](size_t o) { return *reinterpret_cast<const f32x4*>(x + o); },
+             [&](size_t, f32x4 v) {
+               v -= K;
+               a1 += v;
+               a2 += v * v;
+             });
     const double s1 = block_sum_d((double)a1[0] + (double)a1[1] + (double)a1[2] + (double)a1[3], red);
     const double s2 = block_sum_d((double)a2[0] + (double)a2[1] + (double)a2[2] + (double)a2[3], red);
     const double d = s1 / (double)cnt;
@@ -2362,22 +2390,25 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
   const float w = weight ? weight[(size_t)g * C + c] : 1.0f, b = bias ? bias[(size_t)g * C + c] : 0.0f;
   const float sc = w * rstd, sh = b - mean * sc;
   float amax = 0.f;
-  for (int n = m.ni; n < N; n += m.ipp) {
-    const size_t o = base + (size_t)n * nstride;
-    for (int q = m.si; q < m.s4; q += m.tpi) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + o + 4 * q);
-      f32x4 r;
+  bn_sweep(m, N, base, nstride,
+           [&](size_t o) {
+             BnPair p;
+             p.v = *reinterpret_cast<const f32x4*>(x + o);
+             p.d = res ? *reinterpret_cast<const f32x4*>(res + o) : f32x4{0.f, 0.f, 0.f, 0.f};      // fused residual add
+             return p;
+           },
+           [&](size_t o, const BnPair& p) {
+             f32x4 r;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = fmaf(v[e], sc, sh);
-      if (res) r += *reinterpret_cast<const f32x4*>(res + o + 4 * q);      // fused residual add and relu
-      if (relu) {
+             for (int e = 0; e < 4; ++e) r[e] = fmaf(p.v[e], sc, sh);
+             if (res) r += p.d;
+             if (relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
-      }
-      *reinterpret_cast<f32x4*>(y + o + 4 * q) = r;
-      amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
-    }
-  }
+               for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+             }
+             *reinterpret_cast<f32x4*>(y + o) = r;
+             amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
+           });
   if (ymax) {
     const double mx = block_max_d((double)amax, red);
     if (threadIdx.x == 0) atomicMax(ymax + g, __float_as_uint((float)mx));
@@ -2399,22 +2430,24 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   const float mean = save_mean[(size_t)g * C + c], rstd = save_rstd[(size_t)g * C + c];
   const BnMap m = bn_map(S);
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-  for (int n = m.ni; n < N; n += m.ipp) {
-    const size_t o = base + (size_t)n * nstride;
-    for (int q = m.si; q < m.s4; q += m.tpi) {
-      f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + o + 4 * q);
-      if (yout) {
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(yout + o + 4 * q);
+  auto load3 = [&](size_t o) {
+    BnTriple p;
+    p.d = *reinterpret_cast<const f32x4*>(dy + o);
+    p.v = *reinterpret_cast<const f32x4*>(x + o);
+    p.y = yout ? *reinterpret_cast<const f32x4*>(yout + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+    return p;
+  };
+  bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
+    f32x4 d = p.d;
+    if (yout) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
-        if (dres) *reinterpret_cast<f32x4*>(dres + o + 4 * q) = d;
-      }
-      a1 += d;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a2[e] = fmaf(d[e], (v[e] - mean) * rstd, a2[e]);
+      for (int e = 0; e < 4; ++e) d[e] = p.y[e] > 0.f ? d[e] : 0.f;
+      if (dres) *reinterpret_cast<f32x4*>(dres + o) = d;
     }
-  }
+    a1 += d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a2[e] = fmaf(d[e], (p.v[e] - mean) * rstd, a2[e]);
+  });
   const double sdy = block_sum_d((double)a1[0] + (double)a1[1] + (double)a1[2] + (double)a1[3], red);
   const double sdx = block_sum_d((double)a2[0] + (double)a2[1] + (double)a2[2] + (double)a2[3], red);
   if (threadIdx.x == 0) {
@@ -2425,23 +2458,18 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   const float w = weight ? weight[(size_t)g * C + c] : 1.0f;
   const float k = w * rstd, m1 = training ? (float)(sdy / (double)cnt) : 0.f, m2 = training ? (float)(sdx / (double)cnt) : 0.f;
   float amax = 0.f;
-  for (int n = m.ni; n < N; n += m.ipp) {
-    const size_t o = base + (size_t)n * nstride;
-    for (int q = m.si; q < m.s4; q += m.tpi) {
-      f32x4 d = *reinterpret_cast<const f32x4*>(dy + o + 4 * q);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + o + 4 * q);
-      if (yout) {
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(yout + o + 4 * q);
+  bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
+    f32x4 d = p.d;
+    if (yout) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
-      }
-      f32x4 r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = k * (d[e] - m1 - (v[e] - mean) * rstd * m2);
-      *reinterpret_cast<f32x4*>(dx + o + 4 * q) = r;
-      amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
+      for (int e = 0; e < 4; ++e) d[e] = p.y[e] > 0.f ? d[e] : 0.f;
     }
-  }
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = k * (d[e] - m1 - (p.v[e] - mean) * rstd * m2);
+    *reinterpret_cast<f32x4*>(dx + o) = r;
+    amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
+  });
   if (dxmax) {      // max |dx| per group: the scale of the convolution whose output gradient this is
     const double mx = block_max_d((double)amax, red);
     if (threadIdx.x == 0) atomicMax(dxmax + g, __float_as_uint((float)mx));
