@@ -64,6 +64,23 @@ struct H32Smem {
   alignas(16) unsigned short b[2][2][NN ? (TN / 16) * kH32Panel : TN * 32];
 };
 
+// Streamed launches (run<Stream> with Stream::kOn): ONE workgroup walks several output tiles with the k-tiles of
+// consecutive tiles in one unbroken pipeline - the last two k-tile iterations of a tile already issue the NEXT tile's
+// first two k-tiles' loads and stage its first k-tile, the epilogue's stores go out with those loads in flight, and the
+// next tile's MFMAs start right behind them.  A workgroup launched per tile pays its first loads' full latency, its
+// epilogue and the dispatch of its successor with the matrix cores idle: 13 - 17 us per 256 x 256 dX tile against 38 us
+// of k-loop (tools/dx_fill_probe.py).  Stream: bool next(H32Desc&, Pro&) - the tile after the one being computed, asked
+// for at the start of a tile; void epilogue(tile, smem) - store the finished tile (the controller keeps track of which;
+// stage 1 of the LDS buffers is free at that point - between two barriers of its own).
+struct H32Desc {
+  const void* A;
+  unsigned bytesA;
+  const void* B;
+  unsigned bytesB;
+  int ldb, row0, col0;
+};
+struct H32NoStream { static constexpr bool kOn = false; };
+
 // A [rows, K] (k contiguous); NN = false: B [cols, K]; NN = true: B [K, cols].  rows / cols multiples of the tile,
 // kend - kbeg a multiple of 32, 16-byte aligned rows.  SAMEAB / ASLICED / NT as in GemmTileX6.
 // Pro: prefetch(SET, k) once per k-tile, a whole k-tile before its values are staged (SET = the tile's parity; k = the
@@ -90,9 +107,11 @@ struct GemmTileH32 {
   using Smem = H32Smem<TM, TN, NN>;
   f32x4 acc[MI][NI];
 
+  template <class Stream = H32NoStream>
   __device__ __forceinline__ void run(Smem& sm, const void* Ab, unsigned bytesA, int lda, const void* Bb, unsigned bytesB,
                                       int ldb, int row0, int col0, int kbeg, int kend, Pro& pro, int a_rshift = 31,
-                                      unsigned a_blk = 0, unsigned b_skip = 0, int a_share_row = 0) {
+                                      unsigned a_blk = 0, unsigned b_skip = 0, int a_share_row = 0, Stream* strm = nullptr) {
+    static_assert(!Stream::kOn || (NN && !FOLD && !SAMEAB && !ASLICED && !ASHARE), "streamed tiles: the NN product without local chains");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave / WCOLS, wc = wave % WCOLS, r16 = lane & 15, g = lane >> 4;
     f32x4 loc[MI][NI];   // (unused and optimised away without FOLD)
@@ -104,10 +123,25 @@ struct GemmTileH32 {
     // staging map of a k-contiguous operand: eight consecutive lanes cover the 128 bytes (one cache line) of a row's
     // k-tile, a wave-load is eight whole lines; thread t stages quad kq = t & 7 of rows (t >> 3) + RPK i
     const int kq = t & 7, srow = t >> 3;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Ab), 0, (int)bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Bb), 0, (int)bytesB, 0x00020000);
-    const unsigned sA0 = ((ASLICED ? 0u : (unsigned)row0 * lda) + kbeg) * 4u;
-    const unsigned sB0 = (NN ? ((unsigned)kbeg * ldb + col0) : ((unsigned)col0 * ldb + kbeg)) * 4u;
+    // the operands of the tile being computed (dc) and, in a streamed launch, of the one behind it (dn)
+    struct Ops {
+      __amdgpu_buffer_rsrc_t rsA, rsB;
+      unsigned sA0, sB0;
+      int ldb;
+    };
+    auto make_ops = [&](const void* A_, unsigned bytesA_, const void* B_, unsigned bytesB_, int ldb_, int row0_, int col0_)
+        __attribute__((always_inline)) {
+      Ops o;
+      o.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A_), 0, (int)bytesA_, 0x00020000);
+      o.rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(B_), 0, (int)bytesB_, 0x00020000);
+      o.sA0 = ((ASLICED ? 0u : (unsigned)row0_ * lda) + kbeg) * 4u;
+      o.sB0 = (NN ? ((unsigned)kbeg * ldb_ + col0_) : ((unsigned)col0_ * ldb_ + kbeg)) * 4u;
+      o.ldb = ldb_;
+      return o;
+    };
+    Ops dc = make_ops(Ab, bytesA, Bb, bytesB, ldb, row0, col0), dn = dc;
+    using CUR = std::integral_constant<int, 0>;
+    using NXT = std::integral_constant<int, 1>;
     // (a k-contiguous operand's passes are RPK rows apart: one VGPR offset, the pass in the scalar offset - except for a
     // sliced A, whose rows are not equidistant)
     unsigned aoff[ASLICED ? CA : 1], bgoff[1];
@@ -136,28 +170,30 @@ struct GemmTileH32 {
     using S1 = std::integral_constant<int, 1>;
     f32x4 ra[CA], rb[CB];   // one k-tile (NN: quad i = k-row krow + 8 i)
     // quad i of tile kt (B: index into rb)
-    auto gload_a = [&](int i, int kt) __attribute__((always_inline)) {
+    auto gload_a = [&](int i, int kt, auto SEL) __attribute__((always_inline)) {
       if (ASHARE) return;
-      const unsigned so = sA0 + (unsigned)(kt * kH32BK) * 4u;
-      ra[i] = __builtin_bit_cast(f32x4, ASLICED ? __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[ASLICED ? i : 0], (int)so, 0)
-                                                : __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)aoff[0], (int)(so + i * stepA), 0));
+      const Ops& d = decltype(SEL)::value ? dn : dc;
+      const unsigned so = d.sA0 + (unsigned)(kt * kH32BK) * 4u;
+      ra[i] = __builtin_bit_cast(f32x4, ASLICED ? __builtin_amdgcn_raw_buffer_load_b128(d.rsA, (int)aoff[ASLICED ? i : 0], (int)so, 0)
+                                                : __builtin_amdgcn_raw_buffer_load_b128(d.rsA, (int)aoff[0], (int)(so + i * stepA), 0));
     };
-    auto gload_b = [&](int i, int kt) __attribute__((always_inline)) {
+    auto gload_b = [&](int i, int kt, auto SEL) __attribute__((always_inline)) {
       if (SAMEAB) return;
+      const Ops& d = decltype(SEL)::value ? dn : dc;
       if constexpr (NN) {   // four columns of one k-row: a wave-load is 1 KiB of that row, the row in the scalar offset
-        const int so = (int)(sB0 + (unsigned)(kt * kH32BK + krow + 8 * i) * ldb * 4u);
-        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so, 0));
+        const int so = (int)(d.sB0 + (unsigned)(kt * kH32BK + krow + 8 * i) * d.ldb * 4u);
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rsB, (int)bgoff[0], so, 0));
       } else {
         // (b_skip: the panel's second half may be another block of rows - non-zero for the paired Gram tiles only)
-        const int so = (int)(sB0 + (unsigned)(kt * kH32BK) * 4u + (2 * i >= CB ? b_skip : 0u));
-        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)bgoff[0], so + (int)(i * stepB), 0));
+        const int so = (int)(d.sB0 + (unsigned)(kt * kH32BK) * 4u + (2 * i >= CB ? b_skip : 0u));
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d.rsB, (int)bgoff[0], so + (int)(i * stepB), 0));
       }
     };
     auto gload_all = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < CA; ++i) gload_a(i, kt);
+      for (int i = 0; i < CA; ++i) gload_a(i, kt, CUR{});
 #pragma unroll
-      for (int i = 0; i < CB; ++i) gload_b(i, kt);
+      for (int i = 0; i < CB; ++i) gload_b(i, kt, CUR{});
     };
     auto kpos = [&](int kt) __attribute__((always_inline)) { return kbeg + kt * kH32BK + 4 * kq; };
     // fp16 offsets of this thread's quads in a plane
@@ -248,9 +284,13 @@ struct GemmTileH32 {
     // (Tried for the eight-wave workgroup, whose waves w and w + 4 share a SIMD and run in lockstep behind the barrier: the
     // second four waves staging in the second half of the gaps.  dX 1.54 -> 2.35 ms: their stalls then sit right in
     // front of the barrier, where every wave pays for them.)
-    auto iter = [&](auto PAR, auto FIRST, auto GUARD, int kt) __attribute__((always_inline)) {
+    Pro pron = pro;      // streamed launches: the prologue of the NEXT tile (its operand scales)
+    // LSEL / SSEL (streamed launches): the loads of "tile kt + 2" / the staging of "tile kt + 1" belong to the next
+    // output tile - k-tile ktl = 0 / 1 of it
+    auto iter = [&](auto PAR, auto FIRST, auto GUARD, int kt, auto LSEL, auto SSEL, int ktl) __attribute__((always_inline)) {
       constexpr int BH = decltype(PAR)::value, BL = 1 - BH;
       constexpr bool G = decltype(GUARD)::value;
+      Pro& pst = decltype(SSEL)::value ? pron : pro;
       using SNEXT = std::integral_constant<int, BL>;   // the prologue's register set of tile kt + 1 (tile kt + 2: PAR)
       const int st = kt & 1;
       const bool more = !G || kt + 1 < ntiles;
@@ -265,18 +305,18 @@ struct GemmTileH32 {
           if constexpr (step == 0) {
             if (more_s) {
               if constexpr (isA) {
-                pro.stageA(SNEXT{}, ra[quad], quad);
+                pst.stageA(SNEXT{}, ra[quad], quad);
                 split2h(ra[quad], 0, qv[0], qv[1], 0);
                 split2h(ra[quad], 2, qv[0], qv[1], 1);
               } else {
-                pro.stageB(SNEXT{}, rb[quad], quad);
+                pst.stageB(SNEXT{}, rb[quad], quad);
                 split2h(rb[quad], 0, qv[0], qv[1], 0);
                 split2h(rb[quad], 2, qv[0], qv[1], 1);
               }
             }
             if (load) {
-              if constexpr (isA) { if constexpr ((HECKA_ABL & 32) == 0) gload_a(quad, kt + 2); }
-              else if constexpr ((HECKA_ABL & 64) == 0) gload_b(quad, kt + 2);
+              if constexpr (isA) { if constexpr ((HECKA_ABL & 32) == 0) gload_a(quad, ktl, LSEL); }
+              else if constexpr ((HECKA_ABL & 64) == 0) gload_b(quad, ktl, LSEL);
             }
           } else if (more_s) {
 #pragma unroll
@@ -304,7 +344,7 @@ struct GemmTileH32 {
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr bool RD = (HECKA_ABL & 8) == 0;
-        if constexpr (n == 0) { if (load) pro.prefetch(PAR, kpos(kt + 2)); }
+        if constexpr (n == 0) { if (load) pro.prefetch(PAR, kpos(ktl)); }
         if constexpr (RD && n == 0) rd_b(st, 1, BL);
         if constexpr (RD && n % NB == 1 && i + 1 < MI) rd_a(st, i + 1, (i + 1) & 1);
         if constexpr (n % STRIDE == 0 && n / STRIDE < NITEMS) item(std::integral_constant<int, n / STRIDE>{});
@@ -325,15 +365,51 @@ struct GemmTileH32 {
     };
     std::true_type T;
     std::false_type F;
+    if constexpr (Stream::kOn) {
+      // (ntiles even and >= 4: the stage / register-set parities then run on across output tiles)
+      H32Desc nd;
+      bool has_next = strm->next(nd, pron);
+      while (has_next) {      // every tile but the workgroup's last
+        dn = make_ops(nd.A, nd.bytesA, nd.B, nd.bytesB, nd.ldb, nd.row0, nd.col0);
+        int kt = 0;
+        for (; kt + 4 <= ntiles; kt += 2) {
+          iter(S0{}, F, F, kt, CUR{}, CUR{}, kt + 2);
+          iter(S1{}, F, F, kt + 1, CUR{}, CUR{}, kt + 3);
+        }
+        // the next tile's k-tiles 0 and 1 are loaded, its k-tile 0 staged and its first fragments read
+        iter(S0{}, F, F, kt, NXT{}, CUR{}, 0);
+        iter(S1{}, F, F, kt + 1, NXT{}, NXT{}, 1);
+        strm->epilogue(*this, sm);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dc = dn;
+        pro = pron;
+        has_next = strm->next(nd, pron);
+      }
+      {
+        int kt = 0;
+        for (; kt + 4 <= ntiles; kt += 2) {
+          iter(S0{}, F, F, kt, CUR{}, CUR{}, kt + 2);
+          iter(S1{}, F, F, kt + 1, CUR{}, CUR{}, kt + 3);
+        }
+        iter(S0{}, F, T, kt, CUR{}, CUR{}, kt + 2);
+        iter(S1{}, F, T, kt + 1, CUR{}, CUR{}, kt + 3);
+        strm->epilogue(*this, sm);
+      }
+      return;
+    }
     int kt = 0;
     for (; kt + 4 <= ntiles; kt += 2) {   // steady state: both tiles have two tiles behind them
-      iter(S0{}, T, F, kt);
-      iter(S1{}, F, F, kt + 1);
+      iter(S0{}, T, F, kt, CUR{}, CUR{}, kt + 2);
+      iter(S1{}, F, F, kt + 1, CUR{}, CUR{}, kt + 3);
       fold();
     }
     while (kt < ntiles) {
-      iter(S0{}, T, T, kt++);
-      if (kt < ntiles) iter(S1{}, F, T, kt++);
+      iter(S0{}, T, T, kt, CUR{}, CUR{}, kt + 2);
+      ++kt;
+      if (kt < ntiles) { iter(S1{}, F, T, kt, CUR{}, CUR{}, kt + 2); ++kt; }
       fold();
     }
   }

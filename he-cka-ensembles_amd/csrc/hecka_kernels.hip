@@ -88,6 +88,8 @@ struct Config {
   int ragged_x3;          // HECKA_RAGGED_X3   (-1 = by grid size): 1 / 0 ragged shapes always / never on the masked f16x3 tile
   bool combine_fixg;      // HECKA_COMBINE_FIXG (1): streaming combine keeps its strip's column terms in LDS
   bool combine_x3;        // HECKA_COMBINE_X3 (1): all-layers combine on the fp16 matrix cores when the caller supplies nsq
+  int bwd_stream;         // HECKA_BWD_STREAM (1): all-layers dX as a streamed launch, one workgroup per CU walks the tiles
+                          // (0: a workgroup per tile; n >= 8: at most n workgroups - tests walk many tiles with few)
   bool k32;               // HECKA_K32         (1): all-layers Gram / wide dX on the 32-deep 16x16x32 tile
   bool pairwise_x6;       // HECKA_PAIRWISE_X6 (0): streaming pairwise on the bf16 matrix cores (six-product split)
   int bwd_tn;             // HECKA_BWD_TN      (256): column width of the all-layers dX tile (128: four waves)
@@ -102,6 +104,7 @@ static Config read_config() {
   c.ragged_x3 = (int)num("HECKA_RAGGED_X3", -1);
   c.combine_fixg = num("HECKA_COMBINE_FIXG", 1) != 0;
   c.combine_x3 = num("HECKA_COMBINE_X3", 1) != 0;
+  c.bwd_stream = (int)num("HECKA_BWD_STREAM", 1);
   c.k32 = num("HECKA_K32", 1) != 0;
   c.pairwise_x6 = num("HECKA_PAIRWISE_X6", 0) != 0;
   c.bwd_tn = (int)num("HECKA_BWD_TN", 256);
@@ -115,6 +118,19 @@ static inline const Config& config() { return g_config; }
 extern "C" void hecka_config_reload(void) { g_config = read_config(); }
 
 static long long small_grid() { return config().small_grid; }
+
+// compute units of the current device (cached per device; streamed launches size their grid by it)
+static int device_cus() {
+  static int cus[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
 
 template <bool VEC, bool AMAX>
 __device__ __forceinline__ void colmean_body(const float* __restrict__ X, int B, int P, float* __restrict__ sbar,
@@ -1497,6 +1513,137 @@ __global__ __launch_bounds__(2 * TN, TN == 256 ? 1 : (TM == 256 ? 2 : 3)) void g
     if (i == li) { W = a.l[i].W; X = a.l[i].X; wmax = a.l[i].wmax; xmax = a.l[i].xmax; dX = a.l[i].dX; P = a.l[i].P; }
   gram_bwd_x6_body<1, false, kElemF32, TM, RAGGED, SLICED, TN, K32>(W, X, wmax, xmax, dX, B, P, tilesM, (P + TN - 1) / TN, xcd_map, gate,
                                                               w - w0, a.Mblk, slice_rshift);
+}
+
+// The same launch STREAMED (GemmTileH32::run<Stream>, gemm_f16x3_k32.hpp): one workgroup per CU walks tiles w, w + grid,
+// w + 2 grid, ... of the launch's tile list with the k-tiles of consecutive tiles in one pipeline.  The tile list and the
+// workgroup -> XCD relation are those of gram_bwd_x6_multi_kernel (grid a multiple of 8: tile w still runs on XCD w % 8),
+// so the members' panels are shared through the same L2s.  fp32 features, f16x3, standard W layout, 256 x 256 tiles.
+// (values that are the same in every lane but come out of LDS / vector loads: moved to scalar registers, or the tile
+// descriptors, pointers and scales of the streamed launch would live in vector registers - which the k-loop has none of)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <class T> __device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+struct BwdStream {
+  static constexpr bool kOn = true;
+  const BwdLayerArgs* lay;        // the launch's layer table, in LDS
+  int L, B, tilesM, xcd_map, w, wstep, total;
+  float* out_c; float* out_n;     // the finished / the following tile's first output element
+  int P_c, P_n;
+  float us_c, us_n;
+  __device__ __forceinline__ void decode(int wq, H32Desc& d, ScaleProX6<1>& p, float*& out, int& Pq, float& us) const {
+    int li = 0, w0 = 0;
+    while (li + 1 < L && wq >= lay[li].wg_end) {
+      w0 = lay[li].wg_end;
+      ++li;
+    }
+    li = uni(li);
+    w0 = uni(w0);
+    const BwdLayerArgs la = lay[li];
+    const float* W = uni(la.W);
+    const float* X = uni(la.X);
+    const unsigned* wmax = uni(la.wmax);
+    const float* xmax = uni(la.xmax);
+    float* dX = uni(la.dX);
+    const int P = uni(la.P);
+    int m, tl;
+    member_tile_w(wq - w0, tilesM * (P / 256), xcd_map, m, tl);
+    const int ti = tl % tilesM, tj = tl / tilesM;
+    d.A = W + (size_t)m * B * B;
+    d.bytesA = (unsigned)B * B * 4u;
+    d.B = X + (size_t)m * B * P;
+    d.bytesB = (unsigned)B * P * 4u;
+    d.ldb = P;
+    d.row0 = ti * 256;
+    d.col0 = tj * 256;
+    p.sa = uni(pow2_scale(__uint_as_float(wmax[m]), 14));
+    p.sb = uni(pow2_scale(xmax[m], 14));
+    us = 1.0f / (p.sa * p.sb);
+    out = dX + (size_t)m * B * P + (size_t)(ti * 256) * P + tj * 256;
+    Pq = P;
+  }
+  __device__ __forceinline__ bool next(H32Desc& d, ScaleProX6<1>& p) {
+    w += wstep;
+    if (w >= total) return false;
+    decode(w, d, p, out_n, P_n, us_n);
+    return true;
+  }
+  template <class TileT, class SmemT> __device__ __forceinline__ void epilogue(TileT& t, SmemT& sm) {
+    // Rows through LDS: an MFMA accumulator register holds ONE column of four rows, so storing registers as they lie
+    // writes 64-byte pieces of a row (the 16 lanes of a block) - 6.9 us per 256 x 256 tile, a seventh of the launch
+    // (ablated).  Each wave lays its 16 x 64 row block into a private LDS chunk (pitch 68 floats: the four row groups of a
+    // write fall on disjoint banks) and reads it back with the lanes along the row: four dwordx4 stores of 4 rows x 256
+    // contiguous bytes per block instead of sixteen dword stores.  The chunks lie in stage 1 of the operand buffers, free
+    // here: the last k-tile of this tile has been read (first barrier), the next tile's second k-tile is staged into it
+    // only behind the second barrier.
+    static_assert(TileT::WN == 64 && sizeof(sm.a[1]) >= 4 * 16 * 68 * 4 && sizeof(sm.b[1]) >= 4 * 16 * 68 * 4, "epilogue chunks");
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));      // (recompute the lane's offsets per tile: hoisted out of the tile loop they were spilled)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* chunk = (wave < 4 ? reinterpret_cast<float*>(&sm.a[1][0][0]) : reinterpret_cast<float*>(&sm.b[1][0][0])) + (wave & 3) * (16 * 68);
+    const int r16 = lane & 15, g = lane >> 4;
+    const unsigned P4 = (unsigned)P_c * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out_c, 0, (int)(256u * P4), 0x00020000);
+    // lane (g, r16) stores row g (+ 4 per pass) of the block, columns 4 r16 .. 4 r16 + 3 of the wave's 64; the wave's
+    // own corner goes into the scalar offset
+    const unsigned vo = (unsigned)g * P4 + 16u * (unsigned)r16;
+    const unsigned so = (unsigned)((wave / TileT::WCOLS) * TileT::WM) * P4 + (unsigned)((wave % TileT::WCOLS) * 256);
+    float* const wr_at = chunk + (4 * g) * 68 + r16;        // + q * 68 + 16 j
+    const float* const rd_at = chunk + g * 68 + 4 * r16;    // + 4 pp * 68
+    const float us = us_c;
+    __syncthreads();
+    static_for<TileT::MI>([&](auto I) __attribute__((always_inline)) {
+      constexpr int i = decltype(I)::value;
+      static_for<TileT::NI>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const f32x4 v = t.acc[i][j];
+        static_for<4>([&](auto Q) __attribute__((always_inline)) {
+          constexpr int q = decltype(Q)::value;
+          const float x = v[q];      // (bit-casting the vector ELEMENT expression itself picks element 0 - compiler quirk)
+          wr_at[q * 68 + 16 * j] = x * us;
+        });
+      });
+      static_for<4>([&](auto Pp) __attribute__((always_inline)) {
+        constexpr int pp = decltype(Pp)::value;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(rd_at + 4 * pp * 68);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rs, (int)vo, (int)(so + (16 * i + 4 * pp) * P4), 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+    out_c = out_n;
+    P_c = P_n;
+    us_c = us_n;
+  }
+};
+
+__global__ __launch_bounds__(512, 1) void gram_bwd_stream_kernel(BwdMultiArgs a, int B, int tilesM, int xcd_map,
+                                                                 const float* __restrict__ gate, int total) {
+  using Tile = GemmTileH32<256, 256, true, ScaleProX6<1>, false, false, false, 512>;
+  __shared__ typename Tile::Smem sm;
+  __shared__ BwdLayerArgs lay[kMaxGramLayers];
+#pragma unroll
+  for (int i = 0; i < kMaxGramLayers; ++i)
+    if ((int)threadIdx.x == i) lay[i] = a.l[i];
+  __syncthreads();
+  BwdStream strm{lay, a.L, B, tilesM, xcd_map, (int)blockIdx.x, (int)gridDim.x, total, nullptr, nullptr, 0, 0, 1.f, 1.f};
+  H32Desc d;
+  ScaleProX6<1> pro;
+  if (gate && *gate == 0.f) {      // masked step (ops.grad_gate): exact zeros
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+      strm.decode(w, d, pro, strm.out_c, strm.P_c, strm.us_c);
+      zero_tile(strm.out_c, (size_t)strm.P_c, 0, 0, 256, 256, 256, 256);
+    }
+    return;
+  }
+  strm.decode(strm.w, d, pro, strm.out_c, strm.P_c, strm.us_c);
+  Tile tile;
+  tile.run<BwdStream>(sm, d.A, d.bytesA, B, d.B, d.bytesB, d.ldb, d.row0, d.col0, 0, B, pro, 31, 0u, 0u, 0, &strm);
 }
 
 // General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
@@ -4476,7 +4623,12 @@ int hecka_gram_bwd_multi_f32(int L, const float* const* W, const float* const* X
   if (wide && k32_wanted()) {
     if (slice_rows)
       hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, true, 256, true>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
-    else
+    else if (config().bwd_stream && wg < (1ll << 30)) {
+      // streamed: one workgroup per CU (a multiple of 8, so that tile w keeps running on XCD w % 8)
+      const int cus = config().bwd_stream >= 8 ? config().bwd_stream : device_cus();
+      const unsigned grid = (unsigned)std::min<long long>(wg, std::max(8, cus - cus % 8));
+      hipLaunchKernelGGL(gram_bwd_stream_kernel, dim3(grid), dim3(512), 0, st, a, B, tilesM, xcd, gate, (int)wg);
+    } else
       hipLaunchKernelGGL((gram_bwd_x6_multi_kernel<256, false, false, 256, true>), dim3((unsigned)wg), dim3(512), 0, st, a, B, tilesM, xcd, gate, rs);
   } else if (wide) {
     if (slice_rows)

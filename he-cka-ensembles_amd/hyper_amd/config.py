@@ -17,6 +17,7 @@ class _Knobs(object):
         self.bwd_multi = on('HECKA_BWD_MULTI')            # all layers' dX in one launch
         self.bwd_tn = env('HECKA_BWD_TN', '256')          # column width of the all-layers dX tile (library knob; kernel label here)
         self.k32 = on('HECKA_K32')                        # 32-deep 16x16x32 tile (library knob; kernel label here)
+        self.bwd_stream = on('HECKA_BWD_STREAM')          # streamed all-layers dX launch (library knob; kernel label here)
         self.multi_gram = on('HECKA_MULTI_GRAM')          # all layers' Grams in one launch
         self.fused_layers = on('HECKA_FUSED_LAYERS')      # one autograd node for all layers
         self.fused_ragged = on('HECKA_FUSED_RAGGED')      # ragged layers share the fused node

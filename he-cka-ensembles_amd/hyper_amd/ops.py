@@ -410,6 +410,8 @@ def gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=None, slice_rows=0, slice_members=
         LAST_BWD_KERNEL = 'gram_bwd_x6_multi_kernel<%d, %s, %s, %d, %s>' % (
             tm, 'false' if interior else 'true', 'true' if slice_rows else 'false', 256 if wide else 128,
             'true' if k32 else 'false')
+        if k32 and not slice_rows and knobs.bwd_stream:
+            LAST_BWD_KERNEL = 'gram_bwd_stream_kernel'      # one workgroup per CU walks the 256 x 256 tiles
     return dXs
 
 

@@ -74,6 +74,34 @@ def test_knob_alternative_matches_default(knob, value, shape, tol, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,B,Ps,grid', [(16, 512, (2048, 1024, 512), '1'), (16, 256, (1024, 512, 256), '8'), (5, 256, (768, 256), '16'),
+                                         (3, 1024, (512,), '8'), (8, 512, (256,), '1')])
+def test_streamed_dx_launch_is_bit_equal_to_a_workgroup_per_tile(M, B, Ps, grid, monkeypatch):
+    """HECKA_BWD_STREAM: the all-layers dX launch as one workgroup per CU walking the tiles (the k-tiles of consecutive
+    tiles in one pipeline) against a workgroup per tile - the same products in the same order, so bit for bit; grids capped
+    at 8 / 16 workgroups make every workgroup cross many tile and layer boundaries (odd member counts: no XCD map); a
+    closed gate writes exact zeros."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(M + B)
+    Xs = [torch.randn(M, B, p, device=dev) * (1 + i) for i, p in enumerate(Ps)]
+    Ws = [torch.randn(M, B, B, device=dev) * (0.5 + torch.rand(M, 1, 1, device=dev)) for _ in Ps]
+    wmaxs = [W.abs().amax(dim=(1, 2)).contiguous() for W in Ws]
+    xmaxs = [X.abs().amax(dim=(1, 2)).contiguous() for X in Xs]
+    monkeypatch.setenv('HECKA_BWD_STREAM', '0')
+    want = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)
+    monkeypatch.setenv('HECKA_BWD_STREAM', grid)
+    got = ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs)
+    for a, b, W, X in zip(want, got, Ws, Xs):
+        assert torch.equal(a, b)
+        ref = W.double() @ X.double()
+        assert float((b.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    closed = torch.zeros(1, device=dev)
+    for g in ops.gram_bwd_multi(Ws, Xs, wmaxs, xmaxs, gate=closed):
+        assert not bool(g.any())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('knob,value', [('HECKA_CONV_IMPLICIT', '0'), ('HECKA_CONV_KEEP_COLS_GB', '0')])
 def test_conv_knob_alternative_matches_default(knob, value, monkeypatch):
     """Implicit-GEMM convolution off (explicit im2col / col2im for every conv) / gathered patches never kept for backward."""
