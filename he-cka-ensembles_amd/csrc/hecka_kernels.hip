@@ -96,6 +96,8 @@ struct Config {
   bool x16_exact;         // HECKA_X16_EXACT   (0): 16-bit features on the centred three-product Gram
   bool gram_nosplit;      // HECKA_GRAM_NOSPLIT (0): never split the all-layers Gram over K
   bool gram_pair;         // HECKA_GRAM_PAIR   (1): all-layers Gram on the paired 128 x 256 tiles (0: 128 x 128 tiles)
+  int gram_spec;          // HECKA_GRAM_SPEC   (1): speculative Gram (sampled shift + row-centring) where eligible AND worth it
+                          // (0: always the exact column-mean pass; 2: wherever the shape is eligible - tests)
 };
 static Config read_config() {
   auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; };
@@ -111,6 +113,7 @@ static Config read_config() {
   c.x16_exact = getenv("HECKA_X16_EXACT") != nullptr;
   c.gram_nosplit = getenv("HECKA_GRAM_NOSPLIT") != nullptr;
   c.gram_pair = num("HECKA_GRAM_PAIR", 1) != 0;
+  c.gram_spec = (int)num("HECKA_GRAM_SPEC", 1);
   return c;
 }
 static Config g_config = read_config();
@@ -201,7 +204,10 @@ struct ColmeanMultiArgs {
   int blk_end[kMaxColLayers];
   int L;
 };
-__global__ __launch_bounds__(512) void colmean_multi_kernel(ColmeanMultiArgs a, int B, unsigned* __restrict__ xmax_all, int M) {
+// gate (may be NULL): the launch does nothing while *gate == 0 (the fallback of the speculative Gram)
+__global__ __launch_bounds__(512) void colmean_multi_kernel(ColmeanMultiArgs a, int B, unsigned* __restrict__ xmax_all, int M,
+                                                            const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;
   const int b = blockIdx.x;
   int li = 0, b0 = 0;
   while (li + 1 < a.L && b >= a.blk_end[li]) {
@@ -434,27 +440,37 @@ struct CenterProX6 {
   template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
 
-// The same for the 32-deep tile (gemm_f16x3_k32.hpp): one quad of means per k-tile, four staged rows per thread
-struct CenterProK32 {
+// The same for the 32-deep tile (gemm_f16x3_k32.hpp): one quad of means per k-tile, four staged rows per thread.
+// TRACK (the speculative Gram, gram_center_spec_*): `sbar` is an ESTIMATE of the column means and the scale comes from a
+// sampled maximum, so the prologue also keeps the exact max |x - sbar| it has seen (one v_max3 per two elements).
+template <bool TRACK>
+struct CenterProK32T {
   const float* sbar;
   float s;
   f32x4 s4[2];            // means of this thread's k-quad, per tile parity (fetched a whole k-tile ahead)
   float cav[4], cbv[4];   // per-lane partial dots sbar . (x - sbar), one per staged row (registers are short here)
+  float mx;               // TRACK: max |x - sbar| over everything this thread staged
   template <class S> __device__ __forceinline__ void prefetch(S, int k) {
     s4[S::value] = *reinterpret_cast<const f32x4*>(sbar + k);
   }
   template <class S> __device__ __forceinline__ void stage(S, f32x4& v, float& acc) {
     const f32x4 m4 = s4[S::value];
+    float c[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float c = v[e] - m4[e];
-      acc = fmaf(c, m4[e], acc);
-      v[e] = c * s;
+      c[e] = v[e] - m4[e];
+      acc = fmaf(c[e], m4[e], acc);
+      v[e] = c[e] * s;
+    }
+    if constexpr (TRACK) {   // (fmaxf / fabsf compile to a canonicalising v_max per operand on top: 1.4 instead of 0.5 VALU per element)
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(c[0]), "v"(c[1]));
+      asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(c[2]), "v"(c[3]));
     }
   }
   template <class S> __device__ __forceinline__ void stageA(S t, f32x4& v, int i) { stage(t, v, cav[i]); }
   template <class S> __device__ __forceinline__ void stageB(S t, f32x4& v, int i) { stage(t, v, cbv[i]); }
 };
+using CenterProK32 = CenterProK32T<false>;
 
 // RAW (16-bit features only): the MFMA operand is the feature itself - exact in one fp16 term, ONE product per multiply,
 // products exact - and the centring moves to the epilogue: C[a,b] = K[a,b] - u_a with u_a = x_a . sbar = c_a + |sbar|^2
@@ -646,16 +662,17 @@ __device__ __forceinline__ void gram_center_x6_body(const void* __restrict__ X, 
 // image: 256 rows.  Per member and k-tile the upper triangle of B = 512 costs 1536 staged rows instead of 2048.  The
 // tiles of a member are a host-built table (gram_pair_tiles): blocks of a block row paired left to right, the blocks a
 // row leaves over (all in the last block column) paired through the transpose, a last odd one computed twice.
+constexpr int kSpecHeadroom = 12;   // speculative Gram: sampled max * scale <= 2^12, the exact max may be 16 x that (fp16: 65504)
 struct GramPairTiles {
   unsigned char t[32][3];   // (I, J0, J1) per tile, heaviest (no shared panel) first
   int n;
 };
 
-template <bool ASHARE>
-__device__ __forceinline__ void gram_center_pair_run(GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, false>& out,
+template <bool ASHARE, class Pro>
+__device__ __forceinline__ void gram_center_pair_run(GemmTileH32<128, 256, false, Pro, true, false, false, 512, false>& out,
                                                      H32Smem<128, 256, false>& sm, const char* Xm, unsigned bytes, int P, int I,
-                                                     int J0, int J1, int kbeg, int kend, CenterProK32& pro) {
-  using Tile = GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, ASHARE>;
+                                                     int J0, int J1, int kbeg, int kend, Pro& pro) {
+  using Tile = GemmTileH32<128, 256, false, Pro, true, false, false, 512, ASHARE>;
   Tile tile;
   const unsigned skip = (unsigned)(J1 - J0 - 1) * 128u * (unsigned)P * 4u;     // (unsigned wrap-around for J1 <= J0 is intended)
   tile.run(sm, Xm, bytes, P, Xm, bytes, P, I * 128, J0 * 128, kbeg, kend, pro, 31, 0u, skip, I == J0 ? 0 : 128);
@@ -665,11 +682,18 @@ __device__ __forceinline__ void gram_center_pair_run(GemmTileH32<128, 256, false
     for (int j = 0; j < Tile::NI; ++j) out.acc[i][j] = tile.acc[i][j];
 }
 
+// SPEC (the speculative Gram, hecka_gram_center_spec_multi_f32): `sbar` holds an estimate t of the column means, `xmax`
+// a sampled maximum (scale with one more bit of headroom); the workgroup adds the exact max |x - t| of the rows it staged
+// to xsmax[m] (atomicMax on the bit pattern, one per workgroup).  Everything else - C = Ks + 1 q^T with Ks the Gram of the
+// shifted features and q = t . (x_b - t), cvec = q - is the same code; the row-centring that makes it exact comes after.
+template <bool SPEC>
 __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X, const float* __restrict__ sbar,
                                                       const float* __restrict__ xmax, float* __restrict__ C,
                                                       float* __restrict__ cvec, int B, int P, const GramPairTiles& tiles,
-                                                      int xcd_map, int w, int kbeg, int kend, int slice_rshift, int Mlay) {
-  using Tile = GemmTileH32<128, 256, false, CenterProK32, true, false, false, 512, false>;
+                                                      int xcd_map, int w, int kbeg, int kend, int slice_rshift, int Mlay,
+                                                      unsigned* __restrict__ xsmax) {
+  using Pro = CenterProK32T<SPEC>;
+  using Tile = GemmTileH32<128, 256, false, Pro, true, false, false, 512, false>;
   __shared__ H32Smem<128, 256, false> sm;
   __shared__ float cA[128], cB[256];
   int m, rem;
@@ -680,9 +704,10 @@ __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X
   for (int i = 1; i < 32; ++i)
     if (i == rem) { I = tiles.t[i][0]; J0 = tiles.t[i][1]; J1 = tiles.t[i][2]; }
   const char* Xm = static_cast<const char*>(X) + (size_t)m * B * P * 4u;
-  CenterProK32 pro;
+  Pro pro;
   pro.sbar = sbar + (size_t)m * P;
-  pro.s = pow2_scale(xmax[m], 13);
+  pro.s = pow2_scale(xmax[m], SPEC ? kSpecHeadroom : 13);
+  pro.mx = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) pro.cav[i] = pro.cbv[i] = 0.f;
   const float unscale = 1.0f / (pro.s * pro.s);
@@ -692,6 +717,13 @@ __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X
   else gram_center_pair_run<false>(tile, sm, Xm, (unsigned)B * P * 4u, P, I, J0, J1, kbeg, kend, pro);
   // c_b = sbar . (x_b - sbar): eight consecutive lanes share a staged row; thread t staged A rows (t >> 3) + 64 i, i < 2,
   // and B panel rows (t >> 3) + 64 i, i < 4
+  __shared__ float wmx[8];
+  if constexpr (SPEC) {
+    float mx = pro.mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float a = pro.cav[i], b = pro.cbv[i];
@@ -703,6 +735,14 @@ __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X
     }
   }
   __syncthreads();
+  if constexpr (SPEC) {
+    if (threadIdx.x == 0) {
+      float v = wmx[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v = fmaxf(v, wmx[q]);
+      atomicMax(xsmax + m, __float_as_uint(v));     // (NaN bit patterns order above inf: a NaN feature ends in the fallback)
+    }
+  }
   if (share && threadIdx.x < 128) cA[threadIdx.x] = cB[(I == J0 ? 0 : 128) + threadIdx.x];
   __syncthreads();
   const size_t mstride = slice_rshift < 31 ? ((size_t)B << slice_rshift) : (size_t)B * B;
@@ -821,8 +861,15 @@ __global__ __launch_bounds__(kThreads, 2) void gram_center_x6_multi_kernel(GramM
 
 // The all-layers launch on the paired tiles (gram_center_pair_body): same layer table, split-K slabs and slice-major
 // epilogue as gram_center_x6_multi_kernel, 512 threads, one workgroup per CU.
+// SPEC: see gram_center_pair_body; l[i].xmax then points at the layer's sampled maxima [M] with the exact maxima xsmax [M]
+// 2 M floats behind them (the statistics block of hecka_gram_center_spec_multi_f32).  gate (may be NULL): the launch does
+// nothing unless (*gate != 0) == gate_want - the speculative path's fallback is enqueued unconditionally and runs only
+// when the flag kernel raised the flag.
+template <bool SPEC>
 __global__ __launch_bounds__(512, 1) void gram_center_pair_multi_kernel(GramMultiArgs a, GramPairTiles tiles, int B, int xcd_map,
-                                                                         int slice_rshift) {
+                                                                         int slice_rshift, const int* __restrict__ gate,
+                                                                         int gate_want) {
+  if (gate && (*gate != 0) != (gate_want != 0)) return;
   const int w = blockIdx.x;
   int li = 0, w0 = 0;
   while (li + 1 < a.L && w >= a.l[li].wg_end) {
@@ -848,7 +895,181 @@ __global__ __launch_bounds__(512, 1) void gram_center_pair_multi_kernel(GramMult
     C = Cws + (size_t)z * a.M * B * B;
     cvec = cws + (size_t)z * a.M * B;
   }
-  gram_center_pair_body(X, sbar, xmax, C, cvec, B, P, tiles, xcd_map, wl, kbeg, kend, slice_rshift, nsplit > 1 ? a.M : a.Mblk);
+  unsigned* xsmax = SPEC ? reinterpret_cast<unsigned*>(const_cast<float*>(xmax)) + 2 * (size_t)a.M : nullptr;
+  gram_center_pair_body<SPEC>(X, sbar, xmax, C, cvec, B, P, tiles, xcd_map, wl, kbeg, kend, slice_rshift,
+                              nsplit > 1 ? a.M : a.Mblk, xsmax);
+}
+
+// ---- The speculative Gram: no exact column-mean pass over X -----------------------------------------------------------
+// The exact centring needs the column means, a whole extra pass over the features (a fifth of all the bytes an evaluation
+// moves).  But C = K - rowmean(K) does not care WHICH vector the features are shifted by: with any t and xs = x - t,
+//     Chat[a,b] = xs_a . xs_b + t . xs_b = x_a . xs_b          (what the Gram kernel computes when handed t for the means)
+//     C[a,b]    = x_a . (xs_b - delta),  delta = mean_b xs_b   =>  C = Chat - rowmean(Chat) 1^T
+// and the true c_b = q_b + rho_b - mean(q) - mean(rho) with q_b = t . xs_b (the kernel's cvec) and rho the row means.  t only
+// has to be NEAR the means so that nothing cancels (|delta| << |x - sbar| sqrt(B)): the mean of 16 sample rows.  The f16x3
+// scale wants a bound on |xs| BEFORE the launch: the sampled maximum with 16 x headroom, checked against the exact maximum
+// the prologue tracks; a member past it (a heavy tail outside the sample) raises a flag and the exact two-pass path, enqueued
+// behind, runs instead (gated launches: nothing comes back to the host).
+constexpr int kSpecRows = 16;         // sample rows r * B / 16
+constexpr int kSpecBlk = 1;           // 128-column blocks per workgroup of the estimate pass (one 16-byte load per thread each)
+__global__ __launch_bounds__(512) void colest_multi_kernel(ColmeanMultiArgs a, int B, unsigned* __restrict__ stat, int M, int nblk,
+                                                           int rstride) {
+  __shared__ f32x4 red[kSpecBlk][kSpecRows][32];
+  __shared__ float wred[kSpecBlk][8];
+  const int m = blockIdx.y;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  f32x4 v[kSpecBlk];
+  float* sb[kSpecBlk];
+  int pp[kSpecBlk], PP[kSpecBlk], ll[kSpecBlk];
+#pragma unroll
+  for (int j = 0; j < kSpecBlk; ++j) {
+    const int b = blockIdx.x * kSpecBlk + j;
+    int li = 0, b0 = 0;
+    while (li + 1 < a.L && b >= a.blk_end[li]) {
+      b0 = a.blk_end[li];
+      ++li;
+    }
+    const float* X = a.X[0]; float* sbar = a.sbar[0]; int P = a.P[0];
+#pragma unroll
+    for (int i = 1; i < kMaxColLayers; ++i)
+      if (i == li) { X = a.X[i]; sbar = a.sbar[i]; P = a.P[i]; }
+    if (b >= nblk) P = 0;
+    const int p = ((b - b0) * 32 + cx) * 4;
+    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p < P) v[j] = *reinterpret_cast<const f32x4*>(X + ((size_t)m * B + (size_t)ry * rstride) * P + p);
+    sb[j] = sbar; pp[j] = p; PP[j] = P; ll[j] = li;
+  }
+#pragma unroll
+  for (int j = 0; j < kSpecBlk; ++j) {
+    float mx = fmaxf(fmaxf(fabsf(v[j][0]), fabsf(v[j][1])), fmaxf(fabsf(v[j][2]), fabsf(v[j][3])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wred[j][threadIdx.x >> 6] = mx;
+    red[j][ry][cx] = v[j];
+  }
+  __syncthreads();
+  if (ry == 0) {
+#pragma unroll
+    for (int j = 0; j < kSpecBlk; ++j) {
+      if (PP[j] == 0) continue;
+      unsigned* mest = stat + (size_t)ll[j] * 3 * M;      // [3][M] per layer: sampled max |x|, max |t|, (exact max |x - t|: the Gram launch)
+      f32x4 s = red[j][0][cx];
+#pragma unroll
+      for (int r = 1; r < kSpecRows; ++r) s += red[j][r][cx];
+      s *= 1.0f / (float)kSpecRows;
+      const bool in = pp[j] < PP[j];
+      if (in) *reinterpret_cast<f32x4*>(sb[j] + (size_t)m * PP[j] + pp[j]) = s;
+      float tm = in ? fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3]))) : 0.f;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+      if (threadIdx.x == 0) {
+        atomicMax(mest + M + m, __float_as_uint(tm));
+        float w = wred[j][0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) w = fmaxf(w, wred[j][q]);
+        atomicMax(mest + m, __float_as_uint(w));
+      }
+    }
+  }
+}
+
+// flag = any member whose exact max |x - t| does not fit the scale chosen from the sample (or is not finite).  Clear:
+// xmax_all[l, m] = max |x - t| + max |t| >= max |x| for the dX GEMM; raised: xmax_all zeroed for the fallback's atomicMax.
+__global__ __launch_bounds__(256) void gram_spec_flag_kernel(const unsigned* __restrict__ stat, int L, int M, int* __restrict__ flag,
+                                                             float* __restrict__ xmax_all) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < L * M; i += 256) {
+    const int l = i / M, m = i - l * M;
+    const float me = __uint_as_float(stat[((size_t)l * 3 + 0) * M + m]);
+    const float xs = __uint_as_float(stat[((size_t)l * 3 + 2) * M + m]);
+    if (!(xs * pow2_scale(me, kSpecHeadroom) < 65000.0f)) bad = 1;
+  }
+  bad = __syncthreads_or(bad);
+  for (int i = threadIdx.x; i < L * M; i += 256) {
+    const int l = i / M, m = i - l * M;
+    xmax_all[i] = bad ? 0.f : __uint_as_float(stat[((size_t)l * 3 + 2) * M + m]) + __uint_as_float(stat[((size_t)l * 3 + 1) * M + m]);
+  }
+  if (threadIdx.x == 0) *flag = bad;
+}
+
+struct GramSpecFixArgs {
+  float* C[kMaxGramLayers];
+  float* cvec[kMaxGramLayers];
+};
+
+// C = Chat - rowmean(Chat) 1^T in place, rho = the row means; one wave per row, four rows in flight (grid.y = layer)
+template <int NCH>      // 256-column chunks per row: B <= 256 NCH
+__global__ __launch_bounds__(256) void gram_rowfix_kernel(GramSpecFixArgs a, float* __restrict__ rho_all, long long rows, int B,
+                                                          const int* __restrict__ flag) {
+  if (*flag) return;
+  const int li = blockIdx.y;
+  float* C = a.C[0];
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) C = a.C[i];
+  float* rho = rho_all + (size_t)li * rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r0 = ((long long)blockIdx.x * 4 + wave) * 8;
+  const float inv = 1.0f / (float)B;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 v[4][NCH];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const long long row = r0 + h * 4 + r;
+        const int col = c * 256 + lane * 4;
+        v[r][c] = (row < rows && col < B) ? *reinterpret_cast<const f32x4*>(C + row * B + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long row = r0 + h * 4 + r;
+      f32x4 s4 = v[r][0];
+#pragma unroll
+      for (int c = 1; c < NCH; ++c) s4 += v[r][c];
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      s *= inv;
+      if (row < rows) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < B) *reinterpret_cast<f32x4*>(C + row * B + col) = v[r][c] - f32x4{s, s, s, s};
+        }
+        if (lane == 0) rho[row] = s;
+      }
+    }
+  }
+}
+
+// cvec = q + rho - mean(q) - mean(rho) per (layer, member): grid (M, L), fixed-order sums
+__global__ __launch_bounds__(256) void gram_cvecfix_kernel(GramSpecFixArgs a, const float* __restrict__ rho_all, int M, int B,
+                                                           const int* __restrict__ flag) {
+  if (*flag) return;
+  const int li = blockIdx.y, m = blockIdx.x;
+  float* cv = a.cvec[0];
+#pragma unroll
+  for (int i = 1; i < kMaxGramLayers; ++i)
+    if (i == li) cv = a.cvec[i];
+  cv += (size_t)m * B;
+  const float* rho = rho_all + ((size_t)li * M + m) * B;
+  __shared__ float red[2][256];
+  float sq = 0.f, sr = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) { sq += cv[b]; sr += rho[b]; }
+  red[0][threadIdx.x] = sq;
+  red[1][threadIdx.x] = sr;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  const float off = (red[0][0] + red[1][0]) / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) cv[b] = cv[b] + rho[b] - off;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3122,7 +3343,8 @@ int hecka_colmean_multi_f32(int L, const float* const* X, int M, int B, const in
   if (blocks > 0x7fffffffLL) return fail(HECKA_EINVAL, "colmean_multi: grid too large%s");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(xmax_all, 0, (size_t)L * M * sizeof(unsigned), st) != hipSuccess) return check_launch("colmean_multi (memset)");
-  hipLaunchKernelGGL(colmean_multi_kernel, dim3((unsigned)blocks, M), dim3(512), 0, st, a, B, reinterpret_cast<unsigned*>(xmax_all), M);
+  hipLaunchKernelGGL(colmean_multi_kernel, dim3((unsigned)blocks, M), dim3(512), 0, st, a, B, reinterpret_cast<unsigned*>(xmax_all), M,
+                     (const int*)nullptr);
   return check_launch("colmean_multi");
 }
 
@@ -3458,7 +3680,8 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
     hipLaunchKernelGGL((gram_center_x6_multi_kernel<1, kElemF32, false, true>), dim3((unsigned)wg), dim3(kThreads), 0, st, a, B,
                        ntile, xcd, rs);
   } else if (pair) {
-    hipLaunchKernelGGL(gram_center_pair_multi_kernel, dim3((unsigned)wg), dim3(512), 0, st, a, tiles, B, xcd, rs);
+    hipLaunchKernelGGL(gram_center_pair_multi_kernel<false>, dim3((unsigned)wg), dim3(512), 0, st, a, tiles, B, xcd, rs,
+                       (const int*)nullptr, 0);
   } else if (have_max && g_gemm_mode == HECKA_GEMM_AUTO) {
     bool k32 = k32_wanted();
     for (int i = 0; i < L; ++i) k32 = k32 && P[i] % 32 == 0 && kch[i] % 32 == 0;
@@ -3478,6 +3701,95 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
     return check_launch("gram_center_multi (split reduce)");
   }
   return HECKA_OK;
+}
+
+// ---- the speculative Gram (kernels: colest_multi_kernel ... gram_cvecfix_kernel) ----
+static bool gram_spec_shape_ok(int L, int M, int B, const int* P) {
+  if (L <= 0 || L > kMaxGramLayers || L > kMaxColLayers || M <= 0 || M > 65535 || B <= 0 || !P) return false;
+  const int ntile = B / 128;
+  if (B % 128 != 0 || ntile < 2 || ntile > 8) return false;
+  for (int i = 0; i < L; ++i)
+    if (P[i] <= 0 || P[i] % 32 != 0 || (long long)B * P[i] * 4 >= (1ll << 32) || (i > 0 && P[i] > P[i - 1])) return false;
+  int ns[kMaxGramLayers], kc[kMaxGramLayers];
+  return gram_split_plan(L, M, B, P, ns, kc) == 0;     // big grids only: a split launch keeps the exact path
+}
+
+// Worth it when the column-mean pass it saves (X once, ~5.4 TB/s) outweighs what it adds: the row-centring pass (the Grams
+// read + written, ~6.4 TB/s) and ~60 us of small launches (estimate, flag, cvec, the gated fallback) - deep layers, sum P >> L B.
+int hecka_gram_center_spec_eligible(int L, int M, int B, const int* P) {
+  if (!config().gram_spec || !config().gram_pair || !k32_wanted() || !gram_spec_shape_ok(L, M, B, P)) return 0;
+  if (config().gram_spec >= 2) return 1;
+  double xb = 0.0;
+  for (int i = 0; i < L; ++i) xb += 4.0 * M * B * P[i];
+  const double cb = 4.0 * L * M * (double)B * B;
+  return xb / 5.4e12 > 1.3 * (2.0 * cb / 6.4e12 + 60e-6) ? 1 : 0;
+}
+
+static size_t gram_spec_stat_bytes(int L, int M) { return (((size_t)L * 3 * M + 4) * sizeof(unsigned) + 255) / 256 * 256; }
+
+size_t hecka_gram_center_spec_workspace_bytes(int L, int M, int B, const int* P) {
+  if (!gram_spec_shape_ok(L, M, B, P)) return 0;
+  return gram_spec_stat_bytes(L, M) + (size_t)L * M * B * sizeof(float);
+}
+
+int hecka_gram_center_spec_multi_f32(int L, const float* const* X, float* const* sbar, float* xmax_all, int M, int B,
+                                     const int* P, float* const* C, float* const* cvec, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  clear_error();
+  if (!X || !sbar || !xmax_all || !P || !C || !cvec || !ws) return fail(HECKA_EINVAL, "gram_center_spec: null pointer%s");
+  if (!gram_spec_shape_ok(L, M, B, P) || !config().gram_pair || !k32_wanted())
+    return fail(HECKA_EINVAL, "gram_center_spec: shape not eligible (hecka_gram_center_spec_eligible)%s");
+  const size_t need = hecka_gram_center_spec_workspace_bytes(L, M, B, P);
+  if (ws_bytes < need || !aligned16(ws))
+    return fail(HECKA_EWORKSPACE, "%sgram_center_spec: workspace too small or unaligned (%lld bytes given)", "", (long long)ws_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* stat = static_cast<unsigned*>(ws);                       // [L][3][M]: sampled max, max |t|, exact max |x - t|
+  int* flag = reinterpret_cast<int*>(stat + (size_t)L * 3 * M);
+  float* rho = reinterpret_cast<float*>(static_cast<char*>(ws) + gram_spec_stat_bytes(L, M));
+  ColmeanMultiArgs ca;
+  ca.L = L;
+  GramMultiArgs ga, gx;      // speculative launch (xmax -> the statistics block), exact fallback (xmax -> xmax_all)
+  ga.L = gx.L = L;
+  ga.M = gx.M = ga.Mblk = gx.Mblk = M;
+  GramSpecFixArgs fa;
+  const GramPairTiles tiles = gram_pair_tiles(B / 128);
+  long long blocks = 0, wg = 0;
+  for (int i = 0; i < L; ++i) {
+    if (!X[i] || !sbar[i] || !C[i] || !cvec[i] || !aligned16(X[i]) || !aligned16(sbar[i]) || !aligned16(C[i]))
+      return fail(HECKA_EINVAL, "gram_center_spec: null or unaligned layer pointer%s");
+    blocks += (P[i] + 127) / 128;
+    ca.X[i] = X[i]; ca.sbar[i] = sbar[i]; ca.P[i] = P[i]; ca.blk_end[i] = (int)blocks;
+    wg += (long long)M * tiles.n;
+    ga.l[i] = GramLayerArgs{X[i], sbar[i], reinterpret_cast<const float*>(stat + (size_t)i * 3 * M), C[i], cvec[i], P[i], (int)wg, 1,
+                            P[i], nullptr, nullptr};
+    gx.l[i] = ga.l[i];
+    gx.l[i].xmax = xmax_all + (size_t)i * M;
+    fa.C[i] = C[i];
+    fa.cvec[i] = cvec[i];
+  }
+  for (int i = L; i < kMaxColLayers; ++i) { ca.X[i] = ca.X[L - 1]; ca.sbar[i] = ca.sbar[L - 1]; ca.P[i] = ca.P[L - 1]; ca.blk_end[i] = (int)blocks; }
+  for (int i = L; i < kMaxGramLayers; ++i) { ga.l[i] = ga.l[L - 1]; gx.l[i] = gx.l[L - 1]; fa.C[i] = fa.C[L - 1]; fa.cvec[i] = fa.cvec[L - 1]; }
+  if (blocks > 0x7fffffffLL || wg > 0x7fffffffLL) return fail(HECKA_EINVAL, "gram_center_spec: grid too large%s");
+  const int xcd = (int)(M % 8 == 0);
+  if (hipMemsetAsync(stat, 0, ((size_t)L * 3 * M + 4) * sizeof(unsigned), st) != hipSuccess) return check_launch("gram_center_spec (memset)");
+  hipLaunchKernelGGL(colest_multi_kernel, dim3((unsigned)((blocks + kSpecBlk - 1) / kSpecBlk), M), dim3(512), 0, st, ca, B, stat, M, (int)blocks,
+                     B / kSpecRows);
+  hipLaunchKernelGGL(gram_center_pair_multi_kernel<true>, dim3((unsigned)wg), dim3(512), 0, st, ga, tiles, B, xcd, 31,
+                     (const int*)nullptr, 0);
+  hipLaunchKernelGGL(gram_spec_flag_kernel, dim3(1), dim3(256), 0, st, stat, L, M, flag, xmax_all);
+  const long long rows = (long long)M * B;
+  const dim3 fgrid((unsigned)((rows + 31) / 32), L);
+  if (B <= 256) hipLaunchKernelGGL(gram_rowfix_kernel<1>, fgrid, dim3(256), 0, st, fa, rho, rows, B, flag);
+  else if (B <= 512) hipLaunchKernelGGL(gram_rowfix_kernel<2>, fgrid, dim3(256), 0, st, fa, rho, rows, B, flag);
+  else if (B <= 768) hipLaunchKernelGGL(gram_rowfix_kernel<3>, fgrid, dim3(256), 0, st, fa, rho, rows, B, flag);
+  else hipLaunchKernelGGL(gram_rowfix_kernel<4>, fgrid, dim3(256), 0, st, fa, rho, rows, B, flag);
+  hipLaunchKernelGGL(gram_cvecfix_kernel, dim3(M, L), dim3(256), 0, st, fa, rho, M, B, flag);
+  // the exact path behind it, gated on the flag (a few microseconds of empty workgroups when it is clear)
+  hipLaunchKernelGGL(colmean_multi_kernel, dim3((unsigned)blocks, M), dim3(512), 0, st, ca, B, reinterpret_cast<unsigned*>(xmax_all), M,
+                     (const int*)flag);
+  hipLaunchKernelGGL(gram_center_pair_multi_kernel<false>, dim3((unsigned)wg), dim3(512), 0, st, gx, tiles, B, xcd, 31,
+                     (const int*)flag, 1);
+  return check_launch("gram_center_spec");
 }
 
 size_t hecka_pairwise_workspace_bytes(int Ma, int Mb, long long K) {

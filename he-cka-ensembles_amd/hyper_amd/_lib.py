@@ -42,6 +42,9 @@ SIGNATURES = {
     'hecka_colmean_x16': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'hecka_gram_center_multi_x16': (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     'hecka_gram_center_multi_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
+    'hecka_gram_center_spec_eligible': (_i, [_i, _i, _i, _vp]),
+    'hecka_gram_center_spec_workspace_bytes': (_sz, [_i, _i, _i, _vp]),
+    'hecka_gram_center_spec_multi_f32': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'hecka_gram_bwd_x16': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     'hecka_head_fwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_head_bwd_batched_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

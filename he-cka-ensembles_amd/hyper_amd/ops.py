@@ -16,6 +16,7 @@ from .config import knobs
 # kernel's launches on the launch stream; None in normal operation.
 PROFILE = None
 LAST_BWD_KERNEL = None     # name of the kernel the last dX launch took (bench.py's `roofline.kernel`)
+LAST_SPEC_WS = None        # (workspace, index of its fallback flag) of the last speculative Gram call (tests)
 
 
 # ---- arithmetic of the two large GEMMs (include/hecka.h HECKA_GEMM_*): 0 auto (f16x3), 1 fp32 MFMA, 2 bf16x6 ---------------
@@ -227,6 +228,19 @@ def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
     xmax_all = torch.empty((n, M), device=dev, dtype=torch.float32)
     sbars = [torch.empty((M, X.shape[2]), device=dev, dtype=torch.float32) for X in Xs]
     one_colmean = dt == 0 and all(X.shape[2] % 4 == 0 for X in Xs) and knobs.colmean_multi
+    Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
+    if (one_colmean and not slice_rows and get_gemm_mode() == 0 and M <= 65535
+            and L.hecka_gram_center_spec_eligible(n, M, B, Ps)):
+        # the speculative Gram (include/hecka.h): no column-mean pass over X; sampled shift, row-centred Grams, and the
+        # exact path enqueued behind it on a device flag
+        nbytes = L.hecka_gram_center_spec_workspace_bytes(n, M, B, Ps)
+        ws = torch.empty((nbytes // 4,), device=dev, dtype=torch.float32)
+        _lib.check(L.hecka_gram_center_spec_multi_f32(
+            n, ptrs([Xs[i] for i in order]), ptrs([sbars[i] for i in order]), _p(xmax_all), M, B, Ps,
+            ptrs([C_all[i] for i in order]), ptrs([cvec_all[i] for i in order]), _p(ws), nbytes, st), 'gram_center_spec')
+        global LAST_SPEC_WS
+        LAST_SPEC_WS = (ws, n * 3 * M)      # (tests read the fallback flag: ws.view(int32)[n * 3 * M])
+        return [(C_all[li], cvec_all[li], xmax_all[order.index(li)]) for li in range(n)]
     if one_colmean:      # every layer's column means (and maxima) in one launch, deepest layer first
         _lib.check(L.hecka_colmean_multi_f32(n, ptrs([Xs[i] for i in order]), M, B, (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order]),
                                              ptrs([sbars[i] for i in order]), _p(xmax_all), st), 'colmean_multi')
@@ -239,7 +253,6 @@ def centered_gram_multi(Xs, slice_rows=0, one_buffer=False):
         if not one_colmean:
             _lib.check(L.hecka_colmean_x16(_p(X), dt, M, B, P, _p(sbar), _p(xmax), st), 'colmean')
         out.append((C, cvec, xmax, sbar))
-    Ps = (ctypes.c_int * n)(*[Xs[i].shape[2] for i in order])
     nbytes = L.hecka_gram_center_multi_workspace_bytes(n, M, B, Ps)     # split-K slabs when the grid would be small
     ws = torch.empty((nbytes // 4,), device=dev, dtype=torch.float32) if nbytes else None
     _lib.check(L.hecka_gram_center_multi_x16(

@@ -83,6 +83,26 @@ int hecka_gram_center_f32(const float* X, const float* sbar, const float* xmax, 
 int hecka_gram_center_multi_f32(int L, const float* const* X, const float* const* sbar, const float* const* xmax, int M,
                                 int B, const int* P, float* const* C, float* const* cvec, int gemm_mode, void* stream);
 
+/* hecka_colmean_multi_f32 + hecka_gram_center_multi_f32 WITHOUT the column-mean pass over X ("speculative" Gram; same
+ * outputs: C, cvec, xmax_all - the replacement of linear_gram + center_gram, hyper/diversity/kernels.py:107-127, 335-345).
+ * C = K - rowmean(K) holds for ANY shift t of the features: with xs = x - t the Gram kernel, handed t in place of the
+ * means, writes Chat[a,b] = x_a . xs_b, and C = Chat - rowmean(Chat) 1^T exactly (a row-centring pass over the Grams,
+ * B / P of the bytes of a pass over X), cvec = q + rho - mean(q) - mean(rho) with q = t . xs_b, rho the row means.  t = the
+ * mean of 16 sample rows (near the true means, so nothing cancels); the f16x3 scale comes from the sampled maximum with
+ * 16 x headroom and the Gram prologue tracks the exact max |x - t|: if a member does not fit (a tail the sample missed,
+ * non-finite features) a device flag is raised and the exact two-pass path, enqueued behind and gated on that flag, runs
+ * instead - nothing returns to the host, the call is stream-ordered and capturable like every other.
+ * Eligible: fp32, HECKA_GEMM_AUTO arithmetic, 256 <= B <= 1024 with B % 128 == 0, every P % 32 == 0, layers deepest first,
+ * a grid the all-layers launch does not split over K (hecka_gram_center_spec_eligible; HECKA_GRAM_SPEC=0 turns it off).
+ * sbar[l] ([M,P_l], scratch: holds t, or the exact means after a fallback), xmax_all [L,M] (out: a bound on max |X_m|
+ * for hecka_gram_bwd_*), ws of hecka_gram_center_spec_workspace_bytes bytes, 16-byte aligned; after the call the int at
+ * byte offset 12 L M of ws is 1 if the fallback ran (tests read it). */
+int hecka_gram_center_spec_eligible(int L, int M, int B, const int* P);
+size_t hecka_gram_center_spec_workspace_bytes(int L, int M, int B, const int* P);
+int hecka_gram_center_spec_multi_f32(int L, const float* const* X, float* const* sbar, float* xmax_all, int M, int B,
+                                     const int* P, float* const* C, float* const* cvec, void* ws, size_t ws_bytes,
+                                     void* stream);
+
 /* Pairwise inner products of vectorised Grams: S[i,j] = <Ca[i,:], Cb[j,:]>, Ca [Ma,K], Cb [Mb,K],
  * K = B*B.  Split-K over workgroups with a fixed-order (deterministic) second-stage sum.
  * Replaces vectorize_grams + the matmul of unit_vector_rows outputs (the norms are the diagonal
