@@ -695,7 +695,8 @@ __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X
   using Pro = CenterProK32T<SPEC>;
   using Tile = GemmTileH32<128, 256, false, Pro, true, false, false, 512, false>;
   __shared__ H32Smem<128, 256, false> sm;
-  __shared__ float cA[128], cB[256];
+  __shared__ __attribute__((aligned(16))) float cA[128];
+  __shared__ float cB[256];
   int m, rem;
   member_tile_w(w, tiles.n, xcd_map, m, rem);
   // (kernel-argument table indexed with a runtime index: scalar selects)
@@ -754,13 +755,28 @@ __device__ __forceinline__ void gram_center_pair_body(const void* __restrict__ X
   };
   const int row0 = I * 128;
   if (share && threadIdx.x < 128) cvec[(size_t)m * B + row0 + threadIdx.x] = cA[threadIdx.x];   // block I's diagonal tile is this one
-  tile.for_each([&](int lr, int lc, float v) {
-    const int J = lc < 128 ? J0 : J1;
-    const int col = J * 128 + (lc & 127);
-    v *= unscale;
-    at(row0 + lr, col) = v + cB[lc];
-    if (I != J) at(col, row0 + lr) = v + cA[lr];
-  });
+  // (an accumulator's four elements are four consecutive rows of one column: the mirrored block takes them as ONE 16-byte
+  // store per lane - 16 whole 64-byte pieces per wave-store where element-wise stores touch each of them four times)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / Tile::WCOLS, wc = wave % Tile::WCOLS, r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < Tile::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < Tile::NI; ++j) {
+        const int lc = wc * Tile::WN + j * 16 + r16, lr = wr * Tile::WM + i * 16 + 4 * g;
+        const int J = lc < 128 ? J0 : J1;
+        const int col = J * 128 + (lc & 127);
+        const f32x4 v = tile.acc[i][j] * unscale;
+        const float cb = cB[lc];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) at(row0 + lr + q, col) = v[q] + cb;
+        if (I != J) {
+          const f32x4 ca = *reinterpret_cast<const f32x4*>(&cA[lr]);
+          *reinterpret_cast<f32x4*>(&at(col, row0 + lr)) = v + ca;
+        }
+      }
+  }
 }
 
 template <int SCHEME, bool RAGGED = false>
@@ -3632,7 +3648,7 @@ static int gram_center_multi_impl(int L, const void* const* X, int dtype, const 
   // paired 128 x 256 tiles (gram_center_pair_body): fp32 features, interior shapes, f16x3 on the 32-deep tile
   bool pair = dtype == HECKA_DT_F32 && !ragged && xmax && g_gemm_mode == HECKA_GEMM_AUTO && k32_wanted() && config().gram_pair &&
               ntile >= 2 && ntile <= 8;
-  for (int i = 0; i < L && pair; ++i) pair = xmax[i] && P[i] % 32 == 0 && kch[i] % 32 == 0;
+  for (int i = 0; i < L && pair; ++i) pair = xmax[i] && P[i] % 32 == 0 && kch[i] % 32 == 0 && aligned16(C[i]);   // (16-byte mirrored stores)
   GramPairTiles tiles;
   tiles.n = 0;
   if (pair) {
