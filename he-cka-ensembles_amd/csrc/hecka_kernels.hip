@@ -2582,6 +2582,41 @@ __global__ __launch_bounds__(256) void col2im_s1_kernel(const float* __restrict_
 }
 
 
+// Stride 2 on both axes, no dilation, W % 4 == 0 (the stage transitions of a ResNet: 3 x 3 / pad 1 and the 1 x 1 shortcut): four
+// adjacent pixels per thread as above.  A tap row i reaches image row h only when h + ph - i is even, and of the four
+// pixels exactly the two with the parity of j + pw see tap column j - at two CONSECUTIVE output columns: every patch
+// element is read once, two at a time, and a pixel sums 1, 2 or 4 of them instead of walking all kh kw taps through two
+// integer divisions each (the general kernel: 0.4 - 0.8 ms per transition of the CIFAR ResNet18, 2.4 ms per step).
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float* __restrict__ dcols, ConvGeom g, int R,
+                                                        float* __restrict__ dx) {
+  const unsigned total = (unsigned)g.N * g.C * g.H * g.W;
+  const unsigned e = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (e >= total) return;
+  const int m = blockIdx.y;
+  const unsigned t = e / (unsigned)g.W, w0 = e - t * (unsigned)g.W;
+  const unsigned t2 = t / (unsigned)g.H, h = t - t2 * (unsigned)g.H;
+  const unsigned n = t2 / (unsigned)g.C, c = t2 - n * (unsigned)g.C;
+  const size_t Q = (size_t)g.N * g.Ho * g.Wo;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < g.kh; ++i) {
+    const int hn = (int)h + g.ph - i;
+    if (hn < 0 || (hn & 1)) continue;
+    const int oh = hn >> 1;
+    if (oh >= g.Ho) continue;
+    for (int j = 0; j < g.kw; ++j) {
+      const int p = (j + g.pw) & 1;                       // pixels w0 + p and w0 + p + 2 (w0 is even)
+      const int wn = (int)w0 + p + g.pw - j;              // even; may be negative
+      const int ow = wn >> 1;                             // (arithmetic shift: -2 -> -1)
+      const int r = ((int)c * g.kh + i) * g.kw + j;
+      const float* src = dcols + ((size_t)m * R + r) * Q + ((size_t)n * g.Ho + oh) * g.Wo;
+      if ((unsigned)ow < (unsigned)g.Wo) acc[p] += src[ow];
+      if ((unsigned)(ow + 1) < (unsigned)g.Wo) acc[p + 2] += src[ow + 1];
+    }
+  }
+  *reinterpret_cast<f32x4*>(dx + (size_t)m * total + e) = acc;
+}
+
+
 // ------------------------------------------------------------------------------------------
 // (12) batched BatchNorm: x [G, N, C, S] (G = members, S = H*W), statistics per (member,
 //      channel) over N*S elements.  One workgroup per (channel, member): statistics and normalisation in one launch
@@ -4600,6 +4635,9 @@ int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int 
   const long long total = (long long)N * C * H * W;
   if (sh == 1 && sw == 1 && dh == 1 && dw == 1 && W % 4 == 0 && total < (1ll << 31) && aligned16(dx))
     hipLaunchKernelGGL(col2im_s1_kernel, dim3((unsigned)((total / 4 + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,
+                       dcols, g, rows, dx);
+  else if (sh == 2 && sw == 2 && dh == 1 && dw == 1 && W % 4 == 0 && total < (1ll << 31) && aligned16(dx))
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((total / 4 + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,
                        dcols, g, rows, dx);
   else if (total < (1ll << 31))
     hipLaunchKernelGGL(col2im_kernel<unsigned>, dim3((unsigned)((total + 255) / 256), M), dim3(256), 0, (hipStream_t)stream,

@@ -1418,3 +1418,31 @@ def test_learnable_hyperparameters_step_matches_reference_golden():
     for k in [k[3:] for k in z.files if k.startswith('mg:')]:
         assert got[k].grad is not None, k
         yard.check('mg:' + k, got[k].grad.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,C,H,W,k,pad,stride', [
+    (3, 4, 8, 32, 32, 3, 1, 2),      # a ResNet stage transition: 3 x 3 / pad 1 / stride 2
+    (2, 3, 16, 16, 16, 1, 0, 2),     # its 1 x 1 shortcut
+    (2, 2, 5, 12, 20, 5, 2, 2),      # 5 x 5, rectangular image
+    (1, 2, 3, 10, 8, 4, 1, 2),       # even kernel
+    (2, 2, 4, 9, 12, 3, 0, 2),       # no padding, odd height
+    (2, 2, 4, 9, 10, 3, 1, 2),       # W % 4 != 0: the general kernel
+])
+def test_col2im_stride_two_matches_fold(M, N, C, H, W, k, pad, stride):
+    """hecka_col2im_f32 (the stride-2 gather: two consecutive output columns per tap and pixel pair, parity tests instead
+    of divisions) against torch's fold in fp64 - the adjoint of the patch gather the reference's F.conv2d implies
+    (hyper/layers/conv.py:292-346)."""
+    import torch.nn.functional as F
+    from hyper_amd import _lib
+    dev = torch.device('cuda:0')
+    torch.manual_seed(H * W + k)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    R, Q = C * k * k, N * Ho * Wo
+    dcols = torch.randn(M, R, Q, device=dev)
+    dx = torch.empty(M, N, C, H, W, device=dev)
+    _lib.check(_lib.lib().hecka_col2im_f32(dcols.data_ptr(), M, N, C, H, W, k, k, stride, stride, pad, pad, 1, 1, R, dx.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), 'col2im')
+    ref = torch.stack([F.fold(dcols[m].double().view(R, N, Ho * Wo).permute(1, 0, 2), (H, W), k, padding=pad, stride=stride)
+                       for m in range(M)])
+    assert float((dx.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
