@@ -2763,6 +2763,17 @@ __device__ __forceinline__ void bn_sweep(const BnMap& m, int N, size_t base, siz
     for (int q = m.si; q < m.s4; q += m.tpi) use(o + 4 * (size_t)q, load(o + 4 * (size_t)q));
   }
 }
+// wstride: elements between two members' rows of weight / bias (and of dweight / dbias): C for [G,C] tensors, 2 C when both
+// live in ONE flat [G, 2 C] parameter row (bias = weight + C) - the batched layers' own parameter layout, so no copy is made
+// of either and their gradients come back as one tensor.  run_upd (training): the running statistics [G,C] are updated
+// by the kernel itself, rm = (1 - f) rm + f mean, rv = (1 - f) rv + f var unbias (a dozen [G,C]-sized torch kernels per norm
+// layer otherwise, 4 us each).
+struct BnExtra {
+  int wstride;
+  float* run_mean_upd;
+  float* run_var_upd;
+  float factor, unbias;
+};
 struct BnPair { f32x4 d, v; };
 struct BnTriple { f32x4 d, v, y; };
 
@@ -2773,7 +2784,7 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
                                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd,
                                                                 float* __restrict__ batch_var,
                                                                 const float* __restrict__ res, int relu,
-                                                                unsigned* __restrict__ ymax = nullptr) {
+                                                                unsigned* __restrict__ ymax, BnExtra ex) {
   // ymax (may be NULL): max |y| per group g, one atomic per workgroup - the operand scale of the convolution that
   // reads y next (saves that layer a pass over y)
   __shared__ double red[4];
@@ -2798,6 +2809,12 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
     mean = (float)((double)K + d);
     rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0 && batch_var) batch_var[(size_t)g * C + c] = (float)var;
+    if (threadIdx.x == 0 && ex.run_mean_upd) {
+      float* rm = ex.run_mean_upd + (size_t)g * C + c;
+      float* rv = ex.run_var_upd + (size_t)g * C + c;
+      *rm = *rm * (1.0f - ex.factor) + ex.factor * mean;
+      *rv = *rv * (1.0f - ex.factor) + ex.factor * ((float)var * ex.unbias);
+    }
   } else {
     mean = run_mean[(size_t)g * C + c];
     rstd = 1.0f / sqrtf(run_var[(size_t)g * C + c] + eps);
@@ -2806,7 +2823,7 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
     save_mean[(size_t)g * C + c] = mean;
     save_rstd[(size_t)g * C + c] = rstd;
   }
-  const float w = weight ? weight[(size_t)g * C + c] : 1.0f, b = bias ? bias[(size_t)g * C + c] : 0.0f;
+  const float w = weight ? weight[(size_t)g * ex.wstride + c] : 1.0f, b = bias ? bias[(size_t)g * ex.wstride + c] : 0.0f;
   const float sc = w * rstd, sh = b - mean * sc;
   float amax = 0.f;
   bn_sweep(m, N, base, nstride,
@@ -2839,7 +2856,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ weight, int N, int C, long long S,
                                                                 int training, float* __restrict__ dx, float* __restrict__ dweight,
                                                                 float* __restrict__ dbias, const float* __restrict__ yout,
-                                                                float* __restrict__ dres, unsigned* __restrict__ dxmax = nullptr) {
+                                                                float* __restrict__ dres, unsigned* __restrict__ dxmax, int wstride) {
   // yout (the fused op's output; may be NULL): relu mask, the gradient reaching the normalisation is dy where yout > 0;
   // dres (may be NULL) receives that masked gradient for the residual branch
   __shared__ double red[4];
@@ -2870,11 +2887,11 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   const double sdy = block_sum_d((double)a1[0] + (double)a1[1] + (double)a1[2] + (double)a1[3], red);
   const double sdx = block_sum_d((double)a2[0] + (double)a2[1] + (double)a2[2] + (double)a2[3], red);
   if (threadIdx.x == 0) {
-    if (dweight) dweight[(size_t)g * C + c] = (float)sdx;
-    if (dbias) dbias[(size_t)g * C + c] = (float)sdy;
+    if (dweight) dweight[(size_t)g * wstride + c] = (float)sdx;
+    if (dbias) dbias[(size_t)g * wstride + c] = (float)sdy;
   }
   if (!dx) return;
-  const float w = weight ? weight[(size_t)g * C + c] : 1.0f;
+  const float w = weight ? weight[(size_t)g * wstride + c] : 1.0f;
   const float k = w * rstd, m1 = training ? (float)(sdy / (double)cnt) : 0.f, m2 = training ? (float)(sdx / (double)cnt) : 0.f;
   float amax = 0.f;
   bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
@@ -4657,7 +4674,8 @@ int hecka_batchnorm_fwd_f32(const float* x, int G, int N, int C, long long S, co
   if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_fwd: eval mode needs running statistics%s");
   if (S % 4 == 0 && aligned16(x) && aligned16(y))
     hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
-                       run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, (const float*)nullptr, 0);
+                       run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, (const float*)nullptr, 0,
+                       (unsigned*)nullptr, BnExtra{C, nullptr, nullptr, 0.f, 0.f});
   else
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                        run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var);
@@ -4672,7 +4690,7 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_bwd: size out of range%s");
   if (S % 4 == 0 && aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)))
     hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                       weight, N, C, S, training, dx, dweight, dbias, (const float*)nullptr, (float*)nullptr);
+                       weight, N, C, S, training, dx, dweight, dbias, (const float*)nullptr, (float*)nullptr, (unsigned*)nullptr, C);
   else
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
                        weight, N, C, S, training, dx, dweight, dbias);
@@ -4683,7 +4701,18 @@ int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, 
                                 const float* bias, const float* run_mean, const float* run_var, int training, float eps,
                                 int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, float* ymax,
                                 void* stream) {
+  return hecka_batchnorm_act_fwd_packed_f32(x, res, G, N, C, S, weight, bias, C, run_mean, run_var, training, eps, relu, y,
+                                            save_mean, save_rstd, batch_var, ymax, nullptr, nullptr, 0.f, stream);
+}
+
+int hecka_batchnorm_act_fwd_packed_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
+                                       const float* bias, int wstride, const float* run_mean, const float* run_var,
+                                       int training, float eps, int relu, float* y, float* save_mean, float* save_rstd,
+                                       float* batch_var, float* ymax, float* run_mean_upd, float* run_var_upd, float factor,
+                                       void* stream) {
   clear_error();
+  if (wstride < C || (!run_mean_upd) != (!run_var_upd) || (run_mean_upd && !training))
+    return fail(HECKA_EINVAL, "batchnorm_act_fwd: bad affine stride / running-statistics update outside training%s");
   if (!x || !y || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_fwd: null pointer%s");
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_fwd: size out of range%s");
   if (!training && (!run_mean || !run_var)) return fail(HECKA_EINVAL, "batchnorm_act_fwd: eval mode needs running statistics%s");
@@ -4693,7 +4722,8 @@ int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, 
     return check_launch("batchnorm_act_fwd (memset)");
   hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                      run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, res, relu,
-                     reinterpret_cast<unsigned*>(ymax));
+                     reinterpret_cast<unsigned*>(ymax),
+                     BnExtra{wstride, run_mean_upd, run_var_upd, factor, (float)((double)N * S / (double)std::max<long long>((long long)N * S - 1, 1))});
   return check_launch("batchnorm_act_fwd");
 }
 
@@ -4701,7 +4731,16 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
                                 const float* save_rstd, const float* weight, int G, int N, int C, long long S,
                                 int training, float* dx, float* dres, float* dweight, float* dbias, float* dxmax,
                                 void* stream) {
+  return hecka_batchnorm_act_bwd_packed_f32(dy, x, y, save_mean, save_rstd, weight, C, G, N, C, S, training, dx, dres, dweight,
+                                            dbias, dxmax, stream);
+}
+
+int hecka_batchnorm_act_bwd_packed_f32(const float* dy, const float* x, const float* y, const float* save_mean,
+                                       const float* save_rstd, const float* weight, int wstride, int G, int N, int C,
+                                       long long S, int training, float* dx, float* dres, float* dweight, float* dbias,
+                                       float* dxmax, void* stream) {
   clear_error();
+  if (wstride < C) return fail(HECKA_EINVAL, "batchnorm_act_bwd: bad affine stride%s");
   if (!dy || !x || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_bwd: null pointer%s");
   if (dxmax && !dx) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dxmax needs dx%s");
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_bwd: size out of range%s");
@@ -4711,7 +4750,7 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
   if (dxmax && hipMemsetAsync(dxmax, 0, (size_t)G * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return check_launch("batchnorm_act_bwd (memset)");
   hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                     weight, N, C, S, training, dx, dweight, dbias, y, dres, reinterpret_cast<unsigned*>(dxmax));
+                     weight, N, C, S, training, dx, dweight, dbias, y, dres, reinterpret_cast<unsigned*>(dxmax), wstride);
   return check_launch("batchnorm_act_bwd");
 }
 

@@ -53,7 +53,10 @@ class EnsembleParametersGroupGenerator(nn.Module):
         if getattr(codes, '_hecka_identity', False) and codes.numel() == self.fixed_size:
             # every member, in order (the usual training step): the parameters themselves, no gather in forward and no
             # index_add in backward
-            return torch.cat([v.view(self.fixed_size, -1) for v in self.fixed_parameters.values()], dim=1)
+            vals = list(self.fixed_parameters.values())
+            if len(vals) == 1:      # (a lone weight - every bias-free convolution: a view, not a copy through cat)
+                return vals[0].view(self.fixed_size, -1)
+            return torch.cat([v.view(self.fixed_size, -1) for v in vals], dim=1)
         idx = codes.long().ravel()
         return torch.cat([v.index_select(0, idx).view(len(idx), -1) for v in self.fixed_parameters.values()], dim=1)
 
@@ -75,6 +78,14 @@ class MemberBuffers:
 
     def _all(self, store):
         return getattr(self.idx, '_hecka_identity', False) and self.idx.numel() == store.shape[0]
+
+    def whole(self, name):
+        """Every member, in order: the stacked store itself is the selection (fp32, contiguous, on the GPU)."""
+        store = getattr(self.owner, name)
+        return self._all(store) and store.is_cuda and store.dtype == torch.float32 and store.is_contiguous()
+
+    def store(self, name):
+        return getattr(self.owner, name)
 
     def gather(self, name):
         store = getattr(self.owner, name)

@@ -1,7 +1,9 @@
 """Batched BatchNorm (hyper/layers/norm.py:12-46 `_NormAffine` / `_NormBuffers`, :49-127 `_NormBase`, :129-224
 `_BatchNorm.forward`, BatchNorm1d / BatchNorm2d).  The reference loops F.batch_norm over the ensemble members and stacks;
-here all members go through ONE launch (libhecka hecka_batchnorm_fwd_f32 / _bwd_f32: a workgroup per (member, channel))
-and the running statistics of the selected members are updated with a handful of [members, C] tensor ops."""
+here all members go through ONE launch (libhecka hecka_batchnorm_fwd_f32 / _bwd_f32: a workgroup per (member, channel)).
+On the fused path (hecka_batchnorm_act_*_packed_f32) the kernels read weight | bias from the layer's flat parameter row
+and return their gradients as one tensor, and the forward kernel updates the running statistics itself when every member
+is selected in order; otherwise the selected members' statistics are updated with a handful of [members, C] tensor ops."""
 import torch
 import torch.nn as nn
 
@@ -94,40 +96,50 @@ def cached_absmax(t, rows):
 
 class BatchedBatchNormAct(torch.autograd.Function):
     """y[m] = [relu](batch_norm(x[m], weight[m], bias[m]) [+ res[m]]) in one launch each way (hecka_batchnorm_act_*): the
-    two tails of a ResNet block, norm -> relu and norm -> + shortcut -> relu.  Same by-products as BatchedBatchNorm."""
+    two tails of a ResNet block, norm -> relu and norm -> + shortcut -> relu.  Same by-products as BatchedBatchNorm.
+    packed: `weight` is the layer's flat parameter row [M, 2 C] (weight | bias) as the batched layers keep it - read in
+    place, its gradient returned as one tensor (no slice copies either way); upd = (running mean store, running var
+    store, factor): the kernel updates the running statistics itself (then the returned statistics are not needed)."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, run_mean, run_var, training, eps, relu):
+    def forward(ctx, x, res, weight, bias, run_mean, run_var, training, eps, relu, packed=False, upd=None):
         if not x.is_cuda or x.dtype != torch.float32:
             raise RuntimeError('hyper_amd BatchNorm needs fp32 GPU tensors; there is no CPU path')
         x = x.contiguous()
         res = res.contiguous() if res is not None else None
         M, N, C = x.shape[:3]
         S = int(x[0, 0, 0].numel())
-        w = weight.contiguous() if weight is not None else None
-        b = bias.contiguous() if bias is not None else None
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        if packed:
+            w = weight.contiguous()
+            assert bias is None and tuple(w.shape) == (M, 2 * C) and w.dtype == torch.float32
+            w_ptr, b_ptr, wstride = w.data_ptr(), w.data_ptr() + 4 * C, 2 * C
+        else:
+            w = weight.contiguous() if weight is not None else None
+            b = bias.contiguous() if bias is not None else None
+            w_ptr, b_ptr, wstride = ptr(w), ptr(b), C
         y = torch.empty_like(x)
         ymax = torch.empty((M,), device=x.device, dtype=torch.float32)
         mean = torch.empty((M, C), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        var = torch.empty_like(mean) if training else None
-        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-        _lib.check(_lib.lib().hecka_batchnorm_act_fwd_f32(
-            x.data_ptr(), ptr(res), M, N, C, S, ptr(w), ptr(b), ptr(run_mean), ptr(run_var), int(training), float(eps),
+        var = torch.empty_like(mean) if training and upd is None else None
+        _lib.check(_lib.lib().hecka_batchnorm_act_fwd_packed_f32(
+            x.data_ptr(), ptr(res), M, N, C, S, w_ptr, b_ptr, wstride, ptr(run_mean), ptr(run_var), int(training), float(eps),
             int(bool(relu)), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var), ymax.data_ptr(),
-            torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
+            upd[0].data_ptr() if upd is not None else None, upd[1].data_ptr() if upd is not None else None,
+            float(upd[2]) if upd is not None else 0.0, torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
         tag_absmax(y, ymax)      # the convolution that reads y next takes its operand scale from here
         ctx.save_for_backward(x, mean, rstd, w, y if relu else None)
-        ctx.cfg = (training, S, weight is not None, bias is not None, res is not None)
+        ctx.cfg = (training, S, weight is not None, bias is not None or packed, res is not None, packed)
         if var is None:
-            var = mean.new_zeros(())
+            var = mean if upd is not None else mean.new_zeros(())
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         x, mean, rstd, w, y = ctx.saved_tensors
-        training, S, has_w, has_b, has_res = ctx.cfg
+        training, S, has_w, has_b, has_res, packed = ctx.cfg
         M, N, C = x.shape[:3]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -135,16 +147,22 @@ class BatchedBatchNormAct(torch.autograd.Function):
         dres = None
         if has_res and ctx.needs_input_grad[1]:
             dres = torch.empty_like(x) if y is not None else dy      # no relu: the residual's gradient is dy itself
-        dw = torch.empty_like(mean) if has_w and ctx.needs_input_grad[2] else None
-        db = torch.empty_like(mean) if has_b and ctx.needs_input_grad[3] else None
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-        _lib.check(_lib.lib().hecka_batchnorm_act_bwd_f32(
-            dy.data_ptr(), x.data_ptr(), ptr(y), mean.data_ptr(), rstd.data_ptr(), ptr(w), M, N, C, S, int(training),
-            ptr(dx), ptr(dres) if y is not None else None, ptr(dw), ptr(db), ptr(dxmax),
+        if packed:
+            dw = torch.empty((M, 2 * C), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            db = None
+            dw_ptr, db_ptr, wstride = ptr(dw), (dw.data_ptr() + 4 * C if dw is not None else None), 2 * C
+        else:
+            dw = torch.empty_like(mean) if has_w and ctx.needs_input_grad[2] else None
+            db = torch.empty_like(mean) if has_b and ctx.needs_input_grad[3] else None
+            dw_ptr, db_ptr, wstride = ptr(dw), ptr(db), C
+        _lib.check(_lib.lib().hecka_batchnorm_act_bwd_packed_f32(
+            dy.data_ptr(), x.data_ptr(), ptr(y), mean.data_ptr(), rstd.data_ptr(), ptr(w), wstride, M, N, C, S, int(training),
+            ptr(dx), ptr(dres) if y is not None else None, dw_ptr, db_ptr, ptr(dxmax),
             torch.cuda.current_stream().cuda_stream), 'batchnorm_act_bwd')
         if dx is not None:
             tag_absmax(dx, dxmax)    # dx is the output gradient of the convolution in front of this norm
-        return dx, dres, dw, db, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None
 
 
 def fused_act_eligible(x):
@@ -185,26 +203,33 @@ class _BatchNorm(_NormBase):
         """`residual` / `relu` (not in the reference's signature): y = [relu](norm(input) [+ residual]) as ONE launch when
         the shape allows (fused_act_eligible), else the same thing with torch ops behind the plain norm."""
         self._check_input_dim(input)
-        fused = (relu or residual is not None) and fused_act_eligible(input)
+        fused = fused_act_eligible(input) and (relu or residual is not None or self.affine)
         weight = bias = None
-        if self.affine:
-            viewed = self.affine_module.from_flat(params['affine']['self'])
-            weight, bias = viewed['weight'], viewed['bias']
         bufs = params['norm_buffer']['self'] if self.track_running_stats else None
         bn_training = self.training or not self.track_running_stats
         run_mean = run_var = None
         if bufs is not None and not bn_training:
             run_mean, run_var = bufs.gather('mean'), bufs.gather('var')
+        # the running statistics updated inside the forward kernel: every member in order, a fixed momentum
+        upd = None
+        if fused and self.training and bufs is not None and self.momentum is not None and bufs.whole('mean') and bufs.whole('var'):
+            upd = (bufs.store('mean'), bufs.store('var'), float(self.momentum))
+        flat = params['affine']['self'] if self.affine else None
+        packed = (fused and flat is not None and flat.is_cuda and flat.dtype == torch.float32 and flat.dim() == 2
+                  and flat.shape[1] == 2 * self.num_features)
+        if self.affine and not packed:
+            viewed = self.affine_module.from_flat(flat)
+            weight, bias = viewed['weight'], viewed['bias']
         if fused:
-            y, mean, var = BatchedBatchNormAct.apply(input, residual, weight, bias, run_mean, run_var, bn_training,
-                                                     self.eps, bool(relu))
+            y, mean, var = BatchedBatchNormAct.apply(input, residual, flat if packed else weight, None if packed else bias,
+                                                     run_mean, run_var, bn_training, self.eps, bool(relu), packed, upd)
         else:
             y, mean, var = BatchedBatchNorm.apply(input, weight, bias, run_mean, run_var, bn_training, self.eps)
             if residual is not None:
                 y = y + residual
             if relu:
                 y = torch.relu(y)
-        if self.training and bufs is not None:
+        if self.training and bufs is not None and upd is None:
             cnt = input.shape[1] * int(input[0, 0, 0].numel())
             with torch.no_grad():
                 if self.momentum is None:   # cumulative average (num_batches_tracked is never advanced by the reference)

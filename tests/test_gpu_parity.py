@@ -1446,3 +1446,40 @@ def test_col2im_stride_two_matches_fold(M, N, C, H, W, k, pad, stride):
     ref = torch.stack([F.fold(dcols[m].double().view(R, N, Ho * Wo).permute(1, 0, 2), (H, W), k, padding=pad, stride=stride)
                        for m in range(M)])
     assert float((dx.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('relu,with_res', [(True, True), (True, False), (False, False)])
+def test_packed_batchnorm_equals_the_unpacked_launch(relu, with_res):
+    """hecka_batchnorm_act_*_packed_f32: weight | bias read from the flat [M, 2 C] parameter row, their gradients returned
+    as one tensor, running statistics updated inside the forward kernel - bit-equal outputs and gradients to the
+    unpacked launch, running statistics equal to the [M, C] tensor update it replaces."""
+    from hyper_amd.layers.norm import BatchedBatchNormAct
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    M, N, C, H = 3, 6, 8, 4
+    x0 = torch.randn(M, N, C, H, H, device=dev)
+    r0 = torch.randn_like(x0) if with_res else None
+    flat0 = torch.randn(M, 2 * C, device=dev)
+    rm0, rv0 = torch.randn(M, C, device=dev), torch.rand(M, C, device=dev) + 0.5
+    up = torch.randn_like(x0)
+    factor, cnt = 0.1, N * H * H
+
+    def run(packed):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if r0 is not None else None
+        flat = flat0.clone().requires_grad_(True)
+        rm, rv = rm0.clone(), rv0.clone()
+        if packed:
+            y, mean, var = BatchedBatchNormAct.apply(x, r, flat, None, None, None, True, 1e-5, relu, True, (rm, rv, factor))
+        else:
+            y, mean, var = BatchedBatchNormAct.apply(x, r, flat[:, :C], flat[:, C:], None, None, True, 1e-5, relu)
+            rm.mul_(1 - factor).add_(mean, alpha=factor)
+            rv.mul_(1 - factor).add_(var * (cnt / (cnt - 1)), alpha=factor)
+        (y * up).sum().backward()
+        return y.detach(), x.grad, (r.grad if r is not None else None), flat.grad, rm, rv
+
+    a, b = run(True), run(False)
+    for u, v in zip(a[:4], b[:4]):
+        assert (u is None and v is None) or torch.equal(u, v)
+    assert torch.allclose(a[4], b[4], rtol=1e-6, atol=1e-7) and torch.allclose(a[5], b[5], rtol=1e-6, atol=1e-7)
