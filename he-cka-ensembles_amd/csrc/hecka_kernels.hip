@@ -1949,13 +1949,16 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
                                                                  int N, int Cin, int H, int W,
                                                                  const float* __restrict__ amaxA,
                                                                  const float* __restrict__ amaxB, int amaxB_stride,
-                                                                 float alpha, int tilesM, int tilesN) {
+                                                                 float alpha, int tilesM, int tilesN, int Ho, int Wo, int sh,
+                                                                 int sw) {
+  // (Ho, Wo, sh, sw: the output image and the strides - a pixel q = (n, ho, wo) of the OUTPUT gathers its taps around
+  // input position (ho sh, wo sw); the same-size unit-stride convolutions pass H, W, 1, 1)
   using Tile = GemmTileX6<TM, 128, true, ConvProX3, 1, FOLD>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
   const int ti = tl % tilesM, tj = tl / tilesM;
-  const int S = H * W, Q = N * S;
+  const int S = Ho * Wo, Q = N * S;
   ConvProX3 pro;
   pro.sa = pow2_scale(amaxA[b], 14);
   pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
@@ -1965,14 +1968,15 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
   {
     const int q = tj * 128 + (threadIdx.x & 127);      // the pixel whose taps this thread gathers
     const int n = q / S, rem = q - n * S;
-    pro.h = rem / W;
-    pro.w = rem - pro.h * W;
+    const int ho = rem / Wo;
+    pro.h = ho * sh;
+    pro.w = (rem - ho * Wo) * sw;
     pro.base = (n * Cin * H + pro.h) * W + pro.w;
   }
   const float unscale = alpha / (pro.sa * pro.sb);
   Tile tile;
   tile.run(sm, A + (size_t)b * strideA, (unsigned)((size_t)rows * K * 4u), K, X + (size_t)b * strideX,
-           (unsigned)((size_t)N * Cin * S * 4u), Q, ti * TM, tj * 128, 0, K, pro);
+           (unsigned)((size_t)N * Cin * H * W * 4u), Q, ti * TM, tj * 128, 0, K, pro);
   // NCHW epilogue: this lane's two output pixels (one per 32-column block of the wave's 64 columns)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   size_t obase[2];
@@ -1997,9 +2001,10 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
 struct ConvWgradPro {
   static constexpr bool kImplicitNT = true;
   float sa, sb;
-  int O, C, H, W, S;       // dy channels, x channels, image
-  int n, h, w, cur;        // this thread's quad: q = (n, h, w .. w+3) of k-tile `cur`
-  int dw16, dh16;          // 16 % W, 16 / W
+  int O, C, H, W, S;       // dy channels, x channels, input image; S = Ho Wo (positions of dy per image and channel)
+  int Ho, Wo, sh, sw;      // output image, strides (H, W, 1, 1 for the same-size convolutions)
+  int n, h, w, cur;        // this thread's quad: q = (n, h, w .. w+3) of k-tile `cur`, in OUTPUT coordinates
+  int dw16, dh16;          // 16 % Wo, 16 / Wo
   int arow[2];             // A rows (output channels) of the thread's quads, times S
   int boff[2], bdi[2], bdj[2];   // B rows (taps): element offset, di, dj
   template <class T> __device__ __forceinline__ void prefetch(T, int) {}
@@ -2014,17 +2019,18 @@ struct ConvWgradPro {
   __device__ __forceinline__ void seek(int kt) {
     while (cur < kt) {
       w += dw16;
-      if (w >= W) { w -= W; ++h; }
+      if (w >= Wo) { w -= Wo; ++h; }
       h += dh16;
-      while (h >= H) { h -= H; ++n; }
+      while (h >= Ho) { h -= Ho; ++n; }
       ++cur;
     }
   }
-  __device__ __forceinline__ unsigned avoff(int i) const { return (unsigned)(n * O * S + arow[i] + h * W + w) * 4u; }
+  __device__ __forceinline__ unsigned avoff(int i) const { return (unsigned)(n * O * S + arow[i] + h * Wo + w) * 4u; }
   __device__ __forceinline__ unsigned btoff(int i, int c) const {
-    const int hh = h + bdi[i], ww = w + c + bdj[i];
+    const int h0 = h * sh, w0 = (w + c) * sw;
+    const int hh = h0 + bdi[i], ww = w0 + bdj[i];
     const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-    return ok ? (unsigned)((n * C * H + h) * W + w + c + boff[i]) * 4u : 0xFFFFFFF0u;
+    return ok ? (unsigned)((n * C * H + h0) * W + w0 + boff[i]) * 4u : 0xFFFFFFF0u;
   }
 };
 
@@ -2035,13 +2041,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
                                                                     int W, const float* __restrict__ amaxA,
                                                                     const float* __restrict__ amaxB, int amaxB_stride,
                                                                     float alpha, int tilesM, int tilesN, int kchunk,
-                                                                    long long slab) {
+                                                                    long long slab, int Ho, int Wo, int sh, int sw) {
   using Tile = GemmTileX6<TM, 128, false, ConvWgradPro, 1, true>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
   const int ti = tl % tilesM, tj = tl / tilesM;
-  const int S = H * W, Q = N * S;
+  const int S = Ho * Wo, Q = N * S;
   const int kbeg = blockIdx.y * kchunk;
   int kend = kbeg + kchunk;
   if (kend > Q) kend = Q;
@@ -2049,15 +2055,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
   pro.sa = pow2_scale(amaxA[b], 14);
   pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
   pro.O = O; pro.C = C; pro.H = H; pro.W = W; pro.S = S;
-  pro.dw16 = 16 % W;
-  pro.dh16 = 16 / W;
+  pro.Ho = Ho; pro.Wo = Wo; pro.sh = sh; pro.sw = sw;
+  pro.dw16 = 16 % Wo;
+  pro.dh16 = 16 / Wo;
   {
     const int t = threadIdx.x, kq = t & 3, srow = t >> 2;
     const int q = kbeg + 4 * kq;
     pro.n = q / S;
     const int rem = q - pro.n * S;
-    pro.h = rem / W;
-    pro.w = rem - pro.h * W;
+    pro.h = rem / Wo;
+    pro.w = rem - pro.h * Wo;
     pro.cur = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -2071,7 +2078,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
   const float unscale = (gridDim.y > 1 ? 1.0f : alpha) / (pro.sa * pro.sb);
   Tile tile;
   tile.run(sm, dY + (size_t)b * N * O * S, (unsigned)((size_t)N * O * S * 4u), Q, X + (size_t)b * strideX,
-           (unsigned)((size_t)N * C * S * 4u), Q, ti * TM, tj * 128, kbeg, kend, pro);
+           (unsigned)((size_t)N * C * H * W * 4u), Q, ti * TM, tj * 128, kbeg, kend, pro);
   float* o = out + (size_t)blockIdx.y * slab + (size_t)b * O * Rp;
   tile.for_each([&](int lr, int lc, float v) { o[(size_t)(ti * TM + lr) * Rp + tj * 128 + lc] = v * unscale; });
 }
@@ -4523,35 +4530,48 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
   return HECKA_OK;
 }
 
-int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, int W) {
-  const long long S = (long long)H * W, Q = (long long)N * S;
-  return batch > 0 && rows > 0 && K > 0 && N > 0 && Cin > 0 && H > 0 && W > 0 &&
+int hecka_conv_x3_strided_eligible(int batch, int rows, int K, int N, int Cin, int H, int W, int Ho, int Wo) {
+  const long long S = (long long)Ho * Wo, Q = (long long)N * S;
+  return batch > 0 && rows > 0 && K > 0 && N > 0 && Cin > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 &&
          rows % 64 == 0 && Q % 128 == 0 && K % kX6BK == 0 && (long long)rows * K < (1ll << 30) &&
-         (long long)N * Cin * S < (1ll << 30) && (long long)N * rows * S < (1ll << 31) &&
+         (long long)N * Cin * H * W < (1ll << 30) && (long long)N * rows * S < (1ll << 31) &&
          (long long)batch * (rows / 64) * (Q / 128) < (1ll << 31);
 }
 
-int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
-                      long long strideA, long long strideX, int N, int Cin, int H, int W, float alpha, const float* amaxA,
-                      const float* amaxB, int amaxB_stride, void* stream) {
+int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, int W) {
+  return hecka_conv_x3_strided_eligible(batch, rows, K, N, Cin, H, W, H, W);
+}
+
+int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                              long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                              float alpha, const float* amaxA, const float* amaxB, int amaxB_stride, void* stream) {
   clear_error();
   if (!A || !X || !Y || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_x3: null pointer%s");
-  if (!hecka_conv_x3_eligible(batch, rows, K, N, Cin, H, W) || !aligned16(A) || (strideA % 4) ||
+  if (sh <= 0 || sw <= 0 || (long long)(Ho - 1) * sh >= H + 64 || (long long)(Wo - 1) * sw >= W + 64)
+    return fail(HECKA_EINVAL, "conv_x3: stride / output size do not belong to this input%s");
+  if (!hecka_conv_x3_strided_eligible(batch, rows, K, N, Cin, H, W, Ho, Wo) || !aligned16(A) || (strideA % 4) ||
       (reinterpret_cast<uintptr_t>(tab) & 7))
-    return fail(HECKA_EINVAL, "conv_x3: needs HECKA_GEMM_AUTO, rows %% 64 == 0, N H W %% 128 == 0, K %% 16 == 0%s");
+    return fail(HECKA_EINVAL, "conv_x3: needs HECKA_GEMM_AUTO, rows %% 64 == 0, N Ho Wo %% 128 == 0, K %% 16 == 0%s");
   const int tm = rows % 128 ? 64 : 128;
-  const int tilesM = rows / tm, tilesN = (int)((long long)N * H * W / 128);
+  const int tilesM = rows / tm, tilesN = (int)((long long)N * Ho * Wo / 128);
   dim3 grid((unsigned)((long long)batch * tilesM * tilesN));
   hipStream_t st = (hipStream_t)stream;
   const int2* t2 = reinterpret_cast<const int2*>(tab);
   const bool fold = K > 1024;
 #define HECKA_CX3(FOLDV, TMV) \
   hipLaunchKernelGGL((conv_x3_kernel<FOLDV, TMV>), grid, dim3(kThreads), 0, st, A, X, Y, t2, rows, K, strideA, strideX, N, Cin, H, \
-                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN)
+                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, Ho, Wo, sh, sw)
   if (tm == 128) { if (fold) HECKA_CX3(true, 128); else HECKA_CX3(false, 128); }
   else { if (fold) HECKA_CX3(true, 64); else HECKA_CX3(false, 64); }
 #undef HECKA_CX3
   return check_launch("conv_x3");
+}
+
+int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                      long long strideA, long long strideX, int N, int Cin, int H, int W, float alpha, const float* amaxA,
+                      const float* amaxB, int amaxB_stride, void* stream) {
+  return hecka_conv_x3_strided_f32(A, X, Y, tab, batch, rows, K, strideA, strideX, N, Cin, H, W, H, W, 1, 1, alpha, amaxA, amaxB,
+                                   amaxB_stride, stream);
 }
 
 static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
@@ -4561,28 +4581,39 @@ static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
   return want >= 2 ? (int)want : 1;
 }
 
-int hecka_conv_wgrad_x3_eligible(int batch, int O, int Rp, int N, int C, int H, int W) {
-  const long long S = (long long)H * W, Q = (long long)N * S;
-  return batch > 0 && O > 0 && Rp > 0 && N > 0 && C > 0 && H > 0 && W > 0 && O % 64 == 0 &&
-         Rp % 128 == 0 && Q % 16 == 0 && W % 4 == 0 && (W >= 16 ? W % 16 == 0 : 16 % W == 0) &&
-         (long long)N * O * S < (1ll << 30) && (long long)N * C * S < (1ll << 30) && Q < (1ll << 31) &&
+int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo) {
+  const long long S = (long long)Ho * Wo, Q = (long long)N * S;
+  return batch > 0 && O > 0 && Rp > 0 && N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && O % 64 == 0 &&
+         Rp % 128 == 0 && Q % 16 == 0 && Wo % 4 == 0 && (Wo >= 16 ? Wo % 16 == 0 : 16 % Wo == 0) &&
+         (long long)N * O * S < (1ll << 30) && (long long)N * C * H * W < (1ll << 30) && Q < (1ll << 31) &&
          (long long)batch * O * Rp < (1ll << 31);
 }
 
-size_t hecka_conv_wgrad_x3_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W) {
-  if (!hecka_conv_wgrad_x3_eligible(batch, O, Rp, N, C, H, W)) return 0;
-  const int ns = conv_wgrad_nsplit(batch, O, Rp, (long long)N * H * W);
+int hecka_conv_wgrad_x3_eligible(int batch, int O, int Rp, int N, int C, int H, int W) {
+  return hecka_conv_wgrad_x3_strided_eligible(batch, O, Rp, N, C, H, W, H, W);
+}
+
+size_t hecka_conv_wgrad_x3_strided_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo) {
+  if (!hecka_conv_wgrad_x3_strided_eligible(batch, O, Rp, N, C, H, W, Ho, Wo)) return 0;
+  const int ns = conv_wgrad_nsplit(batch, O, Rp, (long long)N * Ho * Wo);
   return ns > 1 ? (size_t)ns * batch * O * Rp * sizeof(float) : 0;
 }
 
-int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
-                            long long strideX, int N, int C, int H, int W, float alpha, const float* amaxA,
-                            const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes, void* stream) {
+size_t hecka_conv_wgrad_x3_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W) {
+  return hecka_conv_wgrad_x3_strided_workspace_bytes(batch, O, Rp, N, C, H, W, H, W);
+}
+
+int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
+                                    long long strideX, int N, int C, int H, int W, int Ho, int Wo, int sh, int sw, float alpha,
+                                    const float* amaxA, const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes,
+                                    void* stream) {
   clear_error();
   if (!dY || !X || !dW || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_wgrad_x3: null pointer%s");
-  if (!hecka_conv_wgrad_x3_eligible(batch, O, Rp, N, C, H, W) || !aligned16(dY) || (reinterpret_cast<uintptr_t>(tab) & 7))
+  if (sh <= 0 || sw <= 0) return fail(HECKA_EINVAL, "conv_wgrad_x3: bad stride%s");
+  if (!hecka_conv_wgrad_x3_strided_eligible(batch, O, Rp, N, C, H, W, Ho, Wo) || !aligned16(dY) ||
+      (reinterpret_cast<uintptr_t>(tab) & 7))
     return fail(HECKA_EINVAL, "conv_wgrad_x3: shape not eligible (see hecka_conv_wgrad_x3_eligible)%s");
-  const long long Q = (long long)N * H * W;
+  const long long Q = (long long)N * Ho * Wo;
   const int ns = conv_wgrad_nsplit(batch, O, Rp, Q);
   const size_t need = ns > 1 ? (size_t)ns * batch * O * Rp * sizeof(float) : 0;
   if (need && (!ws || ws_bytes < need)) return fail(HECKA_EWORKSPACE, "%sconv_wgrad_x3: workspace too small (%lld bytes given)", "", (long long)ws_bytes);
@@ -4596,10 +4627,10 @@ int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const in
   const int2* t2 = reinterpret_cast<const int2*>(tab);
   if (tm == 128)
     hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
-                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab);
+                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw);
   else
     hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
-                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab);
+                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw);
   if (int rc = check_launch("conv_wgrad_x3")) return rc;
   if (ns > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)slab,
@@ -4607,6 +4638,13 @@ int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const in
     return check_launch("conv_wgrad_x3 (reduce)");
   }
   return HECKA_OK;
+}
+
+int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
+                            long long strideX, int N, int C, int H, int W, float alpha, const float* amaxA,
+                            const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes, void* stream) {
+  return hecka_conv_wgrad_x3_strided_f32(dY, X, dW, tab, batch, O, Rp, strideX, N, C, H, W, H, W, 1, 1, alpha, amaxA, amaxB,
+                                         amaxB_stride, ws, ws_bytes, stream);
 }
 
 static int conv_geom(ConvGeom& g, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,

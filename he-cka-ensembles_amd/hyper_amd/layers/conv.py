@@ -70,18 +70,31 @@ def _conv_tab(Cin, H, W, kh, kw, ph, pw, device, rows=None):
 
 
 def _conv_x3_ok(geom, M, rows, K, N, Cin, H, W):
+    """The implicit-GEMM convolution with the output as large as the input (unit stride, 'same' padding): the forward of
+    most layers and every input gradient that runs as a convolution of dy with the rotated weights."""
     kh, kw, sh, sw, ph, pw, dh, dw = geom
     return (knobs.conv_implicit and knobs.conv_x3
             and sh == 1 and sw == 1 and dh == 1 and dw == 1 and 2 * ph == kh - 1 and 2 * pw == kw - 1
             and ops.get_gemm_mode() == 0 and bool(_lib.lib().hecka_conv_x3_eligible(M, rows, K, N, Cin, H, W)))
 
 
-def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride):
-    """Y [M,N,rows,H,W] = alpha * implicit-GEMM convolution of X [M|1,N,Cin,H,W] with A [M,rows,K] (see include/hecka.h)."""
-    Y = torch.empty((M, N, rows, H, W), device=X.device, dtype=torch.float32)
-    _lib.check(_lib.lib().hecka_conv_x3_f32(A.data_ptr(), X.data_ptr(), Y.data_ptr(), tab.data_ptr(), M, rows, K, rows * K,
-                                            sX, N, Cin, H, W, float(alpha), amaxA.data_ptr(), amaxB.data_ptr(),
-                                            int(amaxB_stride), torch.cuda.current_stream().cuda_stream), 'conv_x3')
+def _conv_x3_fwd_ok(geom, M, rows, K, N, Cin, H, W, Ho, Wo):
+    """The FORWARD convolution as an implicit GEMM: any stride and zero padding, no dilation (the stage transitions of a
+    ResNet - 3 x 3 / stride 2 and the 1 x 1 / stride 2 shortcut - besides the same-size layers)."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    return (knobs.conv_implicit and knobs.conv_x3 and dh == 1 and dw == 1 and ops.get_gemm_mode() == 0
+            and bool(_lib.lib().hecka_conv_x3_strided_eligible(M, rows, K, N, Cin, H, W, Ho, Wo)))
+
+
+def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride, out_hw=None, stride=(1, 1)):
+    """Y [M,N,rows,Ho,Wo] = alpha * implicit-GEMM convolution of X [M|1,N,Cin,H,W] with A [M,rows,K] (see include/hecka.h);
+    out_hw / stride default to the same-size unit-stride case."""
+    Ho, Wo = out_hw if out_hw is not None else (H, W)
+    Y = torch.empty((M, N, rows, Ho, Wo), device=X.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_conv_x3_strided_f32(A.data_ptr(), X.data_ptr(), Y.data_ptr(), tab.data_ptr(), M, rows, K, rows * K,
+                                                    sX, N, Cin, H, W, Ho, Wo, int(stride[0]), int(stride[1]), float(alpha),
+                                                    amaxA.data_ptr(), amaxB.data_ptr(), int(amaxB_stride),
+                                                    torch.cuda.current_stream().cuda_stream), 'conv_x3')
     return Y
 
 
@@ -138,7 +151,7 @@ class BatchedConv2d(torch.autograd.Function):
             ctx.save_for_backward(x5, W, None, None, None)
             ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
             return y
-        if not has_bias and _conv_x3_ok(geom, M, O, K, N, C, H, Wd):
+        if not has_bias and _conv_x3_fwd_ok(geom, M, O, K, N, C, H, Wd, Ho, Wo):
             # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
             Wf = W.reshape(M, O, K).contiguous()
             xmax = (cached_absmax(x, Mx) if not shared else None)
@@ -146,7 +159,8 @@ class BatchedConv2d(torch.autograd.Function):
                 xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
             wmax = _absmax_rows(Wf.reshape(M, -1), M)
             y = _conv_x3(Wf, x5, M, O, K, 0 if shared else N * C * H * Wd, N, C, H, Wd,
-                         _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device), scale, wmax, xmax, 0 if shared else 1)
+                         _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device), scale, wmax, xmax, 0 if shared else 1,
+                         (Ho, Wo), (geom[2], geom[3]))
             ctx.save_for_backward(x5, W, None, xmax, wmax)
             ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
             return y
@@ -219,19 +233,20 @@ class BatchedConv2d(torch.autograd.Function):
         need_dgrad = ctx.needs_input_grad[0] and dx is None
         Rp = (K + 127) // 128 * 128
         L = _lib.lib()
-        if (ctx.needs_input_grad[1] and not has_bias and dymax is not None and geom[2:] == (1, 1, geom[4], geom[5], 1, 1)
-                and 2 * geom[4] == kh - 1 and 2 * geom[5] == kw - 1 and knobs.conv_implicit
+        if (ctx.needs_input_grad[1] and not has_bias and dymax is not None and geom[6:] == (1, 1) and knobs.conv_implicit
                 and knobs.conv_x3 and ops.get_gemm_mode() == 0
-                and L.hecka_conv_wgrad_x3_eligible(M, O, Rp, N, C, H, Wd)):
-            # weight gradient with both operands implicit: dy as it lies (NCHW), patches gathered in the kernel
+                and L.hecka_conv_wgrad_x3_strided_eligible(M, O, Rp, N, C, H, Wd, Ho, Wo)):
+            # weight gradient with both operands implicit: dy as it lies (NCHW), patches gathered in the kernel (any stride
+            # and zero padding: output position (ho, wo) reads the input around (ho sh, wo sw))
             dWp = torch.empty((M, O, Rp), device=dy.device, dtype=torch.float32)
-            nbytes = L.hecka_conv_wgrad_x3_workspace_bytes(M, O, Rp, N, C, H, Wd)
+            nbytes = L.hecka_conv_wgrad_x3_strided_workspace_bytes(M, O, Rp, N, C, H, Wd, Ho, Wo)
             ws = torch.empty((max(nbytes, 4) // 4,), device=dy.device, dtype=torch.float32)
-            _lib.check(L.hecka_conv_wgrad_x3_f32(
+            _lib.check(L.hecka_conv_wgrad_x3_strided_f32(
                 dy.data_ptr(), x5.data_ptr(), dWp.data_ptr(),
                 _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], dy.device, rows=Rp).data_ptr(), M, O, Rp,
-                0 if shared else N * C * H * Wd, N, C, H, Wd, float(scale), dymax.data_ptr(), xmax.data_ptr(),
-                0 if shared else 1, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), 'conv_wgrad_x3')
+                0 if shared else N * C * H * Wd, N, C, H, Wd, Ho, Wo, int(geom[2]), int(geom[3]), float(scale),
+                dymax.data_ptr(), xmax.data_ptr(), 0 if shared else 1, ws.data_ptr(), nbytes,
+                torch.cuda.current_stream().cuda_stream), 'conv_wgrad_x3')
             dW = dWp[:, :, :K].reshape(W.shape)
         if dW is not None and not need_dgrad:
             return dx, dW, db, None, None, None

@@ -312,6 +312,23 @@ int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const in
                             long long strideX, int N, int C, int H, int W, float alpha, const float* amaxA,
                             const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes, void* stream);
 
+/* The two kernels above for ANY stride and zero padding (no dilation) - the stage transitions of a ResNet, 3 x 3 / stride 2
+ * and the 1 x 1 / stride 2 shortcut (hyper/target/resnet.py:23-75; hyper/layers/conv.py:292-346): an OUTPUT position (ho, wo)
+ * gathers its taps around input position (ho sh, wo sw); tab as above with di = i - ph, dj = j - pw.  Y / dY
+ * [batch,N,rows | O,Ho,Wo], X [batch | shared,N,Cin,H,W].  N Ho Wo % 128 == 0 (forward), Wo % 16 == 0 or 16 % Wo == 0 (weight
+ * gradient).  The unstrided entry points are these with Ho = H, Wo = W, sh = sw = 1.  (The INPUT gradient of a strided
+ * convolution stays a GEMM + hecka_col2im_f32, whose stride-2 gather reads every patch element once.) */
+int hecka_conv_x3_strided_eligible(int batch, int rows, int K, int N, int Cin, int H, int W, int Ho, int Wo);
+int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                              long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                              float alpha, const float* amaxA, const float* amaxB, int amaxB_stride, void* stream);
+int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
+size_t hecka_conv_wgrad_x3_strided_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
+int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
+                                    long long strideX, int N, int C, int H, int W, int Ho, int Wo, int sh, int sw, float alpha,
+                                    const float* amaxA, const float* amaxB, int amaxB_stride, void* ws, size_t ws_bytes,
+                                    void* stream);
+
 /* Batched-weight Conv2d as grouped GEMMs (hyper/layers/conv.py:434-502 loops F.conv2d over the
  * members).  hecka_im2col_f32 gathers patches of x [Mx,N,C,H,W] (Mx = members, or 1 for an input shared by all
  * members) into cols [Mx,R,Q], R = C*kh*kw (+1 row of ones when ones_row: the bias then rides through the GEMM as an

@@ -1483,3 +1483,37 @@ def test_packed_batchnorm_equals_the_unpacked_launch(relu, with_res):
     for u, v in zip(a[:4], b[:4]):
         assert (u is None and v is None) or torch.equal(u, v)
     assert torch.allclose(a[4], b[4], rtol=1e-6, atol=1e-7) and torch.allclose(a[5], b[5], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,stride,pad,H,W,N,C,O,shared', [
+    ((3, 3), (2, 2), (1, 1), 16, 16, 8, 64, 128, False),     # a ResNet stage transition
+    ((1, 1), (2, 2), (0, 0), 16, 16, 8, 64, 128, False),     # its 1 x 1 shortcut
+    ((3, 3), (2, 2), (1, 1), 8, 8, 32, 128, 64, True),       # 4 x 4 outputs (four image rows per k-tile), shared input
+    ((5, 3), (2, 1), (2, 1), 8, 16, 8, 64, 64, False),       # rectangular kernel, stride 2 along one axis only
+    ((3, 3), (1, 1), (0, 0), 10, 18, 8, 64, 64, False),      # unit stride without padding: the output is smaller
+])
+def test_strided_implicit_conv_matches_fp64(k, stride, pad, H, W, N, C, O, shared):
+    """hecka_conv_x3_strided_f32 / hecka_conv_wgrad_x3_strided_f32: forward and weight gradient of strided (and unpadded)
+    convolutions as implicit GEMMs - an output position gathers its taps around (ho sh, wo sw) - and the input gradient
+    through the GEMM + stride-aware col2im, against F.conv2d per member in fp64 (hyper/layers/conv.py:292-346)."""
+    import torch.nn.functional as F
+    from hyper_amd.layers.conv import BatchedConv2d, _conv_x3_fwd_ok, _out_size
+    dev = _dev()
+    torch.manual_seed(sum(k) + H + W + stride[0])
+    M = 2
+    geom = (k[0], k[1], stride[0], stride[1], pad[0], pad[1], 1, 1)
+    Ho, Wo = _out_size(H, k[0], stride[0], pad[0], 1), _out_size(W, k[1], stride[1], pad[1], 1)
+    assert _conv_x3_fwd_ok(geom, M, O, C * k[0] * k[1], N, C, H, W, Ho, Wo)
+    x = torch.randn(*((N, C, H, W) if shared else (M, N, C, H, W)), device=dev, requires_grad=True)
+    Wt = (torch.randn(M, O, C, k[0], k[1], device=dev) * 0.05).requires_grad_(True)
+    up = torch.randn(M, N, O, Ho, Wo, device=dev)
+    y = BatchedConv2d.apply(x, Wt, None, 1.3, 1.0, geom)
+    assert tuple(y.shape) == (M, N, O, Ho, Wo)
+    (y * up).sum().backward()
+    xd, Wd = x.detach().cpu().double().requires_grad_(True), Wt.detach().cpu().double().requires_grad_(True)
+    yd = torch.stack([F.conv2d(xd if shared else xd[m], 1.3 * Wd[m], None, stride, pad) for m in range(M)])
+    (yd * up.cpu().double()).sum().backward()
+    assert _relerr(y.detach().cpu().numpy(), yd.detach().numpy()) <= RTOL
+    assert _relerr(x.grad.cpu().numpy(), xd.grad.numpy()) <= RTOL
+    assert _relerr(Wt.grad.cpu().numpy(), Wd.grad.numpy()) <= RTOL
