@@ -155,3 +155,52 @@ def test_loss_and_gradients_through_the_speculative_gram(monkeypatch):
     assert abs(l1 - l0) <= 2e-6 * abs(l0)
     for a, b in zip(g1, g0):
         assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+def test_speculative_gram_replays_in_a_hip_graph_including_the_fallback(monkeypatch):
+    """The call is stream-ordered and holds no host decision: captured once, the same graph gives the speculative result for
+    well-behaved features and the exact path's (flag raised on the device, gated launches) when the replayed input has an
+    outlier the sample does not see."""
+    from hyper_amd import ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(31)
+    M, B, Ps = 64, 512, (512, 256, 128, 64)
+    monkeypatch.setenv('HECKA_GRAM_SPEC', '2')
+    good = [torch.randn(M, B, p, device=dev) for p in Ps]
+    bad = [g.clone() for g in good]
+    bad[0][11, 77, 9] = 3e4
+    static = [g.clone() for g in good]
+    ops.centered_gram_multi(static)                    # warm-up outside the capture (module load, allocator)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.centered_gram_multi(static)
+    ws, idx = ops.LAST_SPEC_WS
+    for src, want_flag in ((good, 0), (bad, 1), (good, 0)):
+        for s, x in zip(static, src):
+            s.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert int(ws.view(torch.int32)[idx].item()) == want_flag
+        for X, (C, cvec, xmax) in zip(src, out):
+            Cd, _ = _fp64(X)
+            assert float((C.double() - Cd).abs().max()) <= 5e-6 * float(Cd.abs().max())
+            assert bool((xmax >= X.abs().amax(dim=(1, 2))).all())
+
+
+def test_speculative_gram_eligibility_is_a_host_decision():
+    """hecka_gram_center_spec_eligible needs no GPU: deep layers on unsplit paired-tile grids only (it must pay for the
+    row-centring pass and ~60 us of launches), never for ragged / small / split shapes."""
+    import ctypes
+    from hyper_amd import _lib
+    L = _lib.lib()
+
+    def elig(M, B, Ps):
+        return L.hecka_gram_center_spec_eligible(len(Ps), M, B, (ctypes.c_int * len(Ps))(*Ps))
+    assert elig(64, 512, (8192, 4096, 2048, 1024, 512)) == 1          # the bench
+    assert elig(64, 512, (1024, 512)) == 0                            # shallow: the column-mean pass is cheaper
+    assert elig(8, 512, (8192, 4096, 2048, 1024, 512)) == 0           # a member shard: the launch is split over K
+    assert elig(5, 300, (864, 256)) == 0 and elig(64, 128, (8192, 4096)) == 0      # ragged / a single block
+    assert elig(64, 512, (512, 1024)) == 0                            # layers must come deepest first
+    assert L.hecka_gram_center_spec_workspace_bytes(5, 64, 512, (ctypes.c_int * 5)(8192, 4096, 2048, 1024, 512)) > 0
