@@ -1942,6 +1942,12 @@ struct ConvProX3 {
   }
 };
 
+// Where the (Ho x Wo) result grid of an image lands in Y [.., rows, OH, OW]: position (u, v) at (u esh + eoh, v esw + eow).
+// Dense (the usual case): OH = Ho, OW = Wo, strides 1, offsets 0.  The input gradient of a stride-2 convolution is four such
+// launches, one per parity class of the input pixels, each a unit-stride convolution of dy with that class's taps.
+struct ConvPlace {
+  int OH, OW, esh, esw, eoh, eow;
+};
 template <bool FOLD, int TM>
 __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const float* __restrict__ A, const float* __restrict__ X,
                                                                  float* __restrict__ Y, const int2* __restrict__ tab,
@@ -1950,7 +1956,7 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
                                                                  const float* __restrict__ amaxA,
                                                                  const float* __restrict__ amaxB, int amaxB_stride,
                                                                  float alpha, int tilesM, int tilesN, int Ho, int Wo, int sh,
-                                                                 int sw) {
+                                                                 int sw, ConvPlace pl) {
   // (Ho, Wo, sh, sw: the output image and the strides - a pixel q = (n, ho, wo) of the OUTPUT gathers its taps around
   // input position (ho sh, wo sw); the same-size unit-stride convolutions pass H, W, 1, 1)
   using Tile = GemmTileX6<TM, 128, true, ConvProX3, 1, FOLD>;
@@ -1979,16 +1985,18 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
            (unsigned)((size_t)N * Cin * H * W * 4u), Q, ti * TM, tj * 128, 0, K, pro);
   // NCHW epilogue: this lane's two output pixels (one per 32-column block of the wave's 64 columns)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t oS = (size_t)pl.OH * pl.OW;
   size_t obase[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = tj * 128 + (wave & 1) * 64 + j * 32 + (lane & 31);
-    const int n = q / S;
-    obase[j] = (size_t)n * rows * S + (size_t)(q - n * S);
+    const int n = q / S, rem = q - n * S;
+    const int u = rem / Wo, v = rem - u * Wo;
+    obase[j] = (size_t)n * rows * oS + (size_t)(u * pl.esh + pl.eoh) * pl.OW + (size_t)(v * pl.esw + pl.eow);
   }
-  float* out = Y + (size_t)b * N * rows * S;
+  float* out = Y + (size_t)b * N * rows * oS;
   tile.for_each([&](int lr, int lc, float v) {
-    out[obase[(lc >> 5) & 1] + (size_t)(ti * TM + lr) * S] = v * unscale;
+    out[obase[(lc >> 5) & 1] + (size_t)(ti * TM + lr) * oS] = v * unscale;
   });
 }
 
@@ -4545,8 +4553,20 @@ int hecka_conv_x3_eligible(int batch, int rows, int K, int N, int Cin, int H, in
 int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
                               long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
                               float alpha, const float* amaxA, const float* amaxB, int amaxB_stride, void* stream) {
+  return hecka_conv_x3_placed_f32(A, X, Y, tab, batch, rows, K, strideA, strideX, N, Cin, H, W, Ho, Wo, sh, sw, Ho, Wo, 1, 1, 0, 0,
+                                  alpha, amaxA, amaxB, amaxB_stride, stream);
+}
+
+int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                             long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                             int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                             const float* amaxB, int amaxB_stride, void* stream) {
   clear_error();
   if (!A || !X || !Y || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_x3: null pointer%s");
+  if (esh <= 0 || esw <= 0 || eoh < 0 || eow < 0 || (long long)(Ho - 1) * esh + eoh >= OH || (long long)(Wo - 1) * esw + eow >= OW ||
+      (long long)N * rows * OH * OW >= (1ll << 31))
+    return fail(HECKA_EINVAL, "conv_x3: the result grid does not fit the output image%s");
+  const ConvPlace pl{OH, OW, esh, esw, eoh, eow};
   if (sh <= 0 || sw <= 0 || (long long)(Ho - 1) * sh >= H + 64 || (long long)(Wo - 1) * sw >= W + 64)
     return fail(HECKA_EINVAL, "conv_x3: stride / output size do not belong to this input%s");
   if (!hecka_conv_x3_strided_eligible(batch, rows, K, N, Cin, H, W, Ho, Wo) || !aligned16(A) || (strideA % 4) ||
@@ -4560,7 +4580,7 @@ int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const in
   const bool fold = K > 1024;
 #define HECKA_CX3(FOLDV, TMV) \
   hipLaunchKernelGGL((conv_x3_kernel<FOLDV, TMV>), grid, dim3(kThreads), 0, st, A, X, Y, t2, rows, K, strideA, strideX, N, Cin, H, \
-                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, Ho, Wo, sh, sw)
+                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, Ho, Wo, sh, sw, pl)
   if (tm == 128) { if (fold) HECKA_CX3(true, 128); else HECKA_CX3(false, 128); }
   else { if (fold) HECKA_CX3(true, 64); else HECKA_CX3(false, 64); }
 #undef HECKA_CX3

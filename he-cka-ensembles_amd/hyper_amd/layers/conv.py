@@ -98,6 +98,65 @@ def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB
     return Y
 
 
+def _dgrad_s2_classes(geom, H, W):
+    """Parity classes (a, b) of the input pixels of a stride-2 convolution: the taps that reach a class, their shifts on
+    the dy grid, and the class's pixel grid.  dx[2u + a][2v + b] = sum_{i in I_a, j in J_b} W[.., i, j] dy[u + (a + ph - i) / 2][v +
+    (b + pw - j) / 2]."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    out = []
+    for a in (0, 1):
+        I = [i for i in range(kh) if (a + ph - i) % 2 == 0]
+        U = (H - a + 1) // 2
+        for b in (0, 1):
+            J = [j for j in range(kw) if (b + pw - j) % 2 == 0]
+            V = (W - b + 1) // 2
+            out.append((a, b, I, J, [(a + ph - i) // 2 for i in I], [(b + pw - j) // 2 for j in J], U, V))
+    return out
+
+
+def _dgrad_s2_ok(geom, M, C, O, N, H, W, Ho, Wo):
+    """The input gradient of a stride-2 convolution as four placed implicit GEMMs (hecka_conv_x3_placed_f32)."""
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    if not (knobs.conv_implicit and knobs.conv_x3 and sh == 2 and sw == 2 and dh == 1 and dw == 1 and ops.get_gemm_mode() == 0):
+        return False
+    L = _lib.lib()
+    any_taps = False
+    for a, b, I, J, di, dj, U, V in _dgrad_s2_classes(geom, H, W):
+        if not I or not J or U == 0 or V == 0:
+            continue
+        any_taps = True
+        if not L.hecka_conv_x3_strided_eligible(M, C, O * len(I) * len(J), N, O, Ho, Wo, U, V):
+            return False
+    return any_taps and kh * kw > 1      # (a 1 x 1 kernel fills one class in four: the GEMM + zero-filling col2im is as good)
+
+
+def _dgrad_s2(W, dy, geom, N, H, Wd, Ho, Wo, scale, wmax, dymax):
+    M, O, C, kh, kw = W.shape
+    classes = _dgrad_s2_classes(geom, H, Wd)
+    full = all(I and J and U and V for _, _, I, J, _, _, U, V in classes)
+    dx = (torch.empty if full else torch.zeros)((M, N, C, H, Wd), device=dy.device, dtype=torch.float32)
+    Wp = W.permute(0, 2, 1, 3, 4)                                    # [M, C, O, kh, kw]
+    L = _lib.lib()
+    for a, b, I, J, di, dj, U, V in classes:
+        if not I or not J or U == 0 or V == 0:
+            continue
+        K = O * len(I) * len(J)
+        A = Wp[:, :, :, I][:, :, :, :, J].reshape(M, C, K).contiguous()
+        key = ('dgrad2', O, Ho, Wo, tuple(di), tuple(dj), str(dy.device))
+        if key not in _TABS:
+            o = torch.arange(O, dtype=torch.int64).view(O, 1, 1)
+            ti = torch.tensor(di, dtype=torch.int64).view(1, -1, 1)
+            tj = torch.tensor(dj, dtype=torch.int64).view(1, 1, -1)
+            off = ((o * Ho + ti) * Wo + tj).reshape(-1)
+            pk = ((ti << 16) | (tj & 0xffff)).expand(O, -1, -1).reshape(-1)
+            _TABS[key] = torch.stack([off, pk], dim=1).to(torch.int32).contiguous().to(dy.device)
+        _lib.check(L.hecka_conv_x3_placed_f32(
+            A.data_ptr(), dy.data_ptr(), dx.data_ptr(), _TABS[key].data_ptr(), M, C, K, C * K, N * O * Ho * Wo, N, O, Ho, Wo,
+            U, V, 1, 1, H, Wd, 2, 2, a, b, float(scale), wmax.data_ptr(), dymax.data_ptr(), 1,
+            torch.cuda.current_stream().cuda_stream), 'conv_x3_placed')
+    return dx
+
+
 def _direct_ok(geom, C, O):
     """Few-channel direct convolution (hecka_conv_direct_f32): unit stride, no dilation, equal zero padding on both axes."""
     kh, kw, sh, sw, ph, pw, dh, dw = geom
@@ -229,6 +288,11 @@ class BatchedConv2d(torch.autograd.Function):
             Wrot = W.flip(3, 4).transpose(1, 2).reshape(M, C, O * kh * kw).contiguous()
             dx = _conv_x3(Wrot, dy, M, C, O * kh * kw, N * O * H * Wd, N, O, H, Wd,
                           _conv_tab(O, H, Wd, kh, kw, kh - 1 - geom[4], kw - 1 - geom[5], dy.device), scale, wmax, dymax, 1)
+            dx = dx.sum(0) if shared else dx
+        if (ctx.needs_input_grad[0] and dx is None and dymax is not None and not has_bias
+                and _dgrad_s2_ok(geom, M, C, O, N, H, Wd, Ho, Wo)):
+            # stride 2: one placed implicit GEMM per parity class of the input pixels (no structural zeros, no col2im)
+            dx = _dgrad_s2(W, dy, geom, N, H, Wd, Ho, Wo, scale, wmax, dymax)
             dx = dx.sum(0) if shared else dx
         need_dgrad = ctx.needs_input_grad[0] and dx is None
         Rp = (K + 127) // 128 * 128

@@ -322,6 +322,15 @@ int hecka_conv_x3_strided_eligible(int batch, int rows, int K, int N, int Cin, i
 int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
                               long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
                               float alpha, const float* amaxA, const float* amaxB, int amaxB_stride, void* stream);
+/* hecka_conv_x3_strided_f32 whose (Ho x Wo) result grid is PLACED into a larger output image Y [batch,N,rows,OH,OW] at
+ * (u esh + eoh, v esw + eow).  The input gradient of a stride-2 convolution is four such launches, one per parity class
+ * (a, b) of the input pixels: dx[2u + a][2v + b] = sum over the taps i = a + ph, j = b + pw (mod 2) of the rotated weights
+ * against dy[u + (a + ph - i) / 2][v + (b + pw - j) / 2] - a unit-stride convolution of dy with that class's taps, no
+ * multiply by a structural zero, no patch matrix, no col2im. */
+int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                             long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                             int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                             const float* amaxB, int amaxB_stride, void* stream);
 int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 size_t hecka_conv_wgrad_x3_strided_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,
