@@ -316,8 +316,8 @@ int hecka_conv_wgrad_x3_f32(const float* dY, const float* X, float* dW, const in
  * and the 1 x 1 / stride 2 shortcut (hyper/target/resnet.py:23-75; hyper/layers/conv.py:292-346): an OUTPUT position (ho, wo)
  * gathers its taps around input position (ho sh, wo sw); tab as above with di = i - ph, dj = j - pw.  Y / dY
  * [batch,N,rows | O,Ho,Wo], X [batch | shared,N,Cin,H,W].  N Ho Wo % 128 == 0 (forward), Wo % 16 == 0 or 16 % Wo == 0 (weight
- * gradient).  The unstrided entry points are these with Ho = H, Wo = W, sh = sw = 1.  (The INPUT gradient of a strided
- * convolution stays a GEMM + hecka_col2im_f32, whose stride-2 gather reads every patch element once.) */
+ * gradient).  The unstrided entry points are these with Ho = H, Wo = W, sh = sw = 1.  (The INPUT gradient of a stride-2
+ * convolution is hecka_conv_x3_placed_f32 below; other strides keep the GEMM + hecka_col2im_f32.) */
 int hecka_conv_x3_strided_eligible(int batch, int rows, int K, int N, int Cin, int H, int W, int Ho, int Wo);
 int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
                               long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
