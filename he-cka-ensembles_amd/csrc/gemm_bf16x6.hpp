@@ -121,6 +121,16 @@ struct implicit_b : std::false_type {};
 template <class P>
 struct implicit_b<P, std::void_t<decltype(P::kImplicitB)>> : std::bool_constant<P::kImplicitB> {};
 
+// TAP-MAJOR implicit NN operand (Pro::kImplicitBT = true): the K axis is ordered (tap, channel) and a k-tile holds 16
+// channels of ONE tap, so whether the tap falls inside the image is decided once per k-tile and thread - pro.tile(ktile, vo,
+// so) gives the thread's byte offset (out of range -> a bounds-checked offset that reads as zero) and the wave-uniform
+// byte offset of the tile's first channel; channel e of the tile is pro.hw4 * e further on, in the SCALAR offset of the
+// load: no vector instruction per gathered element.
+template <class P, class = void>
+struct implicit_bt : std::false_type {};
+template <class P>
+struct implicit_bt<P, std::void_t<decltype(P::kImplicitBT)>> : std::bool_constant<P::kImplicitBT> {};
+
 // Likewise for an NT product (Pro::kImplicitNT = true): both operands come from pro - pro.seek(kt) positions it on k-tile
 // kt (calls come with kt increasing by one), pro.avoff(i) is the byte offset of this thread's A quad of row block i,
 // pro.btoff(i, c) that of element c of its B quad (element-wise, so that a quad may straddle an image border).
@@ -153,7 +163,8 @@ struct GemmTileX6 {
   static constexpr int WCOLS = NT / 128;        // wave grid: 2 rows x WCOLS columns
   // ASLICED: the rows of A lie in blocks of 2^a_rshift rows, block b of this member at element offset b * a_blk (the
   // member-sharded path keeps W in the order the all-to-all delivers it: [slice, member, rows of the slice, B])
-  static_assert(!RAGGED || (!implicit_b<Pro>::value && !implicit_nt<Pro>::value), "ragged tiles: explicit operands only");
+  static_assert(!RAGGED || (!implicit_b<Pro>::value && !implicit_nt<Pro>::value && !implicit_bt<Pro>::value),
+                "ragged tiles: explicit operands only");
   static constexpr unsigned kOOB = 0x80000000u;   // a byte offset no (< 2 GiB) operand reaches: the load returns zero
   // SAMEAB (NT, diagonal tile of a symmetric product): the B rows ARE the A rows - nothing is loaded, split or staged
   // for B, its fragments come from the A planes
@@ -236,6 +247,18 @@ struct GemmTileX6 {
       constexpr int S = decltype(SET)::value;
       pro.prefetch(SET, kbeg + kt * kX6BK + 4 * kq);
       if (SAMEAB) return;
+      if constexpr (implicit_bt<Pro>::value) {
+        static_assert(NN, "tap-major implicit operand: NN products");
+        unsigned vo, so;
+        pro.tile(__builtin_amdgcn_readfirstlane(kbeg / kX6BK + kt), vo, so);
+        so += (unsigned)__builtin_amdgcn_readfirstlane(8 * (t / TN)) * pro.hw4;
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            rb[S][i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsB, (int)vo, (int)(so + (unsigned)(4 * i + c) * pro.hw4), 0));
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < CB; ++i) {
         if (NN) {

@@ -98,6 +98,9 @@ struct Config {
   bool gram_pair;         // HECKA_GRAM_PAIR   (1): all-layers Gram on the paired 128 x 256 tiles (0: 128 x 128 tiles)
   int gram_spec;          // HECKA_GRAM_SPEC   (1): speculative Gram (sampled shift + row-centring) where eligible AND worth it
                           // (0: always the exact column-mean pass; 2: wherever the shape is eligible - tests)
+  int layer_products;     // HECKA_LAYER_PRODUCTS (3): products per multiply of the layer GEMMs / convolutions on the fp16 tile
+                          // (3: h.h + h.l + l.h, fp32-grade; 1: h.h only - operands rounded to fp16 after their
+                          // power-of-two scale, fp32 accumulation: the 16-bit compute mode, hecka_set_layer_products)
 };
 static Config read_config() {
   auto num = [](const char* name, long long dflt) { const char* e = getenv(name); return e && *e ? atoll(e) : dflt; };
@@ -114,11 +117,19 @@ static Config read_config() {
   c.gram_nosplit = getenv("HECKA_GRAM_NOSPLIT") != nullptr;
   c.gram_pair = num("HECKA_GRAM_PAIR", 1) != 0;
   c.gram_spec = (int)num("HECKA_GRAM_SPEC", 1);
+  c.layer_products = num("HECKA_LAYER_PRODUCTS", 3) == 1 ? 1 : 3;
   return c;
 }
 static Config g_config = read_config();
 static inline const Config& config() { return g_config; }
 extern "C" void hecka_config_reload(void) { g_config = read_config(); }
+extern "C" int hecka_set_layer_products(int n) {
+  if (n != 1 && n != 3) return -1;
+  const int old = g_config.layer_products;
+  g_config.layer_products = n;
+  return old;
+}
+extern "C" int hecka_get_layer_products(void) { return g_config.layer_products; }
 
 static long long small_grid() { return config().small_grid; }
 
@@ -1886,7 +1897,7 @@ __global__ __launch_bounds__(512, 1) void gram_bwd_stream_kernel(BwdMultiArgs a,
 // General batched product on the fp16-split tile (interior shapes): C[b] = alpha A[b] op(B[b]), operands scaled into
 // fp16 range by powers of two from per-batch maxima (upper bounds are fine), optional split-K (blockIdx.y: partial
 // slabs for a fixed-order second stage).  The convolution GEMMs of the batched-weight layers at 128 and more channels.
-template <bool NN, bool FOLD, int TM = 128>
+template <bool NN, bool FOLD, int TM = 128, bool LOW = true>
 __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                                   float* __restrict__ C, int rows, int cols, int K,
                                                                   long long strideA, long long strideB,
@@ -1894,7 +1905,8 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void bgemm_x3_kernel(const 
                                                                   const float* __restrict__ amaxB, int amaxB_stride,
                                                                   float alpha, int tilesM, int tilesN, int kchunk,
                                                                   long long slab) {
-  using Tile = GemmTileX6<TM, 128, NN, ScaleProX6<1>, 1, FOLD>;   // TM = 64: the 64-channel stages (rows = 64 or 576)
+  // TM = 64: the 64-channel stages (rows = 64 or 576).  LOW = false: one product per multiply (16-bit compute mode)
+  using Tile = GemmTileX6<TM, 128, NN, ScaleProX6<1>, 1, FOLD, kElemF32, kElemF32, LOW, LOW>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
@@ -1937,8 +1949,37 @@ struct ConvProX3 {
   __device__ __forceinline__ unsigned bvoff(int k) const {
     const int2 e = tab[k];
     const int di = e.y >> 16, dj = (int)(short)(e.y & 0xffff);
-    const bool ok = (unsigned)(h + di) < (unsigned)H && (unsigned)(w + dj) < (unsigned)W;
+    const bool ok = ((unsigned)(h + di) < (unsigned)H) & ((unsigned)(w + dj) < (unsigned)W);   // (&: no branch per element)
     return ok ? (unsigned)(base + e.x) * 4u : 0xFFFFFFF0u;
+  }
+};
+
+// The same operand with K ordered (tap, channel), 16 channels of one tap per k-tile (GemmTileX6, kImplicitBT): tab [K / 16]
+// int4 per k-tile = { byte offset of the tile's first channel, byte offset of the tap (di W + dj) * 4, di, dj }, plus one entry
+// of padding: the entry of the NEXT k-tile is fetched (one scalar load) while the current one is used, so the loop never
+// waits for the table.  (The (c, i, j)-ordered form above pays two dependent scalar loads and a branch per gathered element.)
+struct ConvProTapX3 {
+  static constexpr bool kImplicitBT = true;
+  float sa, sb;
+  const int4* tab;
+  int4 nxt;                 // entry of the k-tile the next tile() call is for (calls come with ktile increasing by one)
+  unsigned base4, hw4;      // byte offset of the thread's pixel in channel 0 of its image; bytes per channel
+  int h, w, H, W;
+  template <class S> __device__ __forceinline__ void prefetch(S, int) {}
+  template <class S> __device__ __forceinline__ void stageA(S, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sa;
+  }
+  template <class S> __device__ __forceinline__ void stageB(S, f32x4& v, int) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sb;
+  }
+  __device__ __forceinline__ void tile(int ktile, unsigned& vo, unsigned& so) {
+    const int4 e = nxt;
+    nxt = tab[ktile + 1];
+    const bool ok = ((unsigned)(h + e.z) < (unsigned)H) & ((unsigned)(w + e.w) < (unsigned)W);
+    vo = ok ? base4 + (unsigned)e.y : 0xFFFFFFF0u;
+    so = (unsigned)e.x;
   }
 };
 
@@ -1948,9 +1989,9 @@ struct ConvProX3 {
 struct ConvPlace {
   int OH, OW, esh, esw, eoh, eow;
 };
-template <bool FOLD, int TM>
+template <bool FOLD, int TM, bool LOW = true, bool TAP = false>
 __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const float* __restrict__ A, const float* __restrict__ X,
-                                                                 float* __restrict__ Y, const int2* __restrict__ tab,
+                                                                 float* __restrict__ Y, const void* __restrict__ tab,
                                                                  int rows, int K, long long strideA, long long strideX,
                                                                  int N, int Cin, int H, int W,
                                                                  const float* __restrict__ amaxA,
@@ -1959,16 +2000,17 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
                                                                  int sw, ConvPlace pl) {
   // (Ho, Wo, sh, sw: the output image and the strides - a pixel q = (n, ho, wo) of the OUTPUT gathers its taps around
   // input position (ho sh, wo sw); the same-size unit-stride convolutions pass H, W, 1, 1)
-  using Tile = GemmTileX6<TM, 128, true, ConvProX3, 1, FOLD>;
+  using Pro = std::conditional_t<TAP, ConvProTapX3, ConvProX3>;
+  using Tile = GemmTileX6<TM, 128, true, Pro, 1, FOLD, kElemF32, kElemF32, LOW, LOW>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
   const int ti = tl % tilesM, tj = tl / tilesM;
   const int S = Ho * Wo, Q = N * S;
-  ConvProX3 pro;
+  Pro pro;
   pro.sa = pow2_scale(amaxA[b], 14);
   pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
-  pro.tab = tab;
+  pro.tab = static_cast<decltype(pro.tab)>(tab);
   pro.H = H;
   pro.W = W;
   {
@@ -1977,7 +2019,14 @@ __global__ __launch_bounds__(kThreads, FOLD ? 2 : 3) void conv_x3_kernel(const f
     const int ho = rem / Wo;
     pro.h = ho * sh;
     pro.w = (rem - ho * Wo) * sw;
-    pro.base = (n * Cin * H + pro.h) * W + pro.w;
+    const int base = (n * Cin * H + pro.h) * W + pro.w;
+    if constexpr (TAP) {
+      pro.base4 = (unsigned)base * 4u;
+      pro.hw4 = (unsigned)(H * W) * 4u;
+      pro.nxt = pro.tab[0];
+    } else {
+      pro.base = base;
+    }
   }
   const float unscale = alpha / (pro.sa * pro.sb);
   Tile tile;
@@ -2015,6 +2064,9 @@ struct ConvWgradPro {
   int dw16, dh16;          // 16 % Wo, 16 / Wo
   int arow[2];             // A rows (output channels) of the thread's quads, times S
   int boff[2], bdi[2], bdj[2];   // B rows (taps): element offset, di, dj
+  // of the quad seek() left the thread on (once per k-tile: the multiplications are not paid per gathered element):
+  int h0, w0;              // its input position (h sh, w sw)
+  unsigned aq4, bq4;       // byte offsets of dy[n][0][h][w] and x[n][0][h0][w0]
   template <class T> __device__ __forceinline__ void prefetch(T, int) {}
   template <class T> __device__ __forceinline__ void stageA(T, f32x4& v, int) {
 #pragma unroll
@@ -2032,17 +2084,20 @@ struct ConvWgradPro {
       while (h >= Ho) { h -= Ho; ++n; }
       ++cur;
     }
+    h0 = h * sh;
+    w0 = w * sw;
+    aq4 = (unsigned)(n * O * S + h * Wo + w) * 4u;
+    bq4 = (unsigned)((n * C * H + h0) * W + w0) * 4u;
   }
-  __device__ __forceinline__ unsigned avoff(int i) const { return (unsigned)(n * O * S + arow[i] + h * Wo + w) * 4u; }
+  __device__ __forceinline__ unsigned avoff(int i) const { return aq4 + (unsigned)arow[i] * 4u; }
   __device__ __forceinline__ unsigned btoff(int i, int c) const {
-    const int h0 = h * sh, w0 = (w + c) * sw;
-    const int hh = h0 + bdi[i], ww = w0 + bdj[i];
-    const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-    return ok ? (unsigned)((n * C * H + h0) * W + w0 + boff[i]) * 4u : 0xFFFFFFF0u;
+    const int hh = h0 + bdi[i], ww = w0 + c * sw + bdj[i];
+    const bool ok = ((unsigned)hh < (unsigned)H) & ((unsigned)ww < (unsigned)W);   // (&: no branch per element)
+    return ok ? bq4 + (unsigned)(c * sw + boff[i]) * 4u : 0xFFFFFFF0u;
   }
 };
 
-template <int TM>
+template <int TM, bool LOW = true>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                     float* __restrict__ out, const int2* __restrict__ tab,
                                                                     int O, int Rp, long long strideX, int N, int C, int H,
@@ -2050,7 +2105,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
                                                                     const float* __restrict__ amaxB, int amaxB_stride,
                                                                     float alpha, int tilesM, int tilesN, int kchunk,
                                                                     long long slab, int Ho, int Wo, int sh, int sw) {
-  using Tile = GemmTileX6<TM, 128, false, ConvWgradPro, 1, true>;
+  using Tile = GemmTileX6<TM, 128, false, ConvWgradPro, 1, true, kElemF32, kElemF32, LOW, LOW>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
@@ -4516,18 +4571,19 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
   hipStream_t st = (hipStream_t)stream;
   float* out = ns > 1 ? (float*)ws : C;
   const long long slab = (long long)batch * rows * cols;
+  const bool low = config().layer_products != 1;
+#define HECKA_BX3_(NNV, FOLDV, TMV, LOWV) \
+  hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV, TMV, LOWV>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, \
+                     strideB, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab)
 #define HECKA_BX3(NNV, FOLDV) \
   do { \
-    if (tm == 128) \
-      hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV, 128>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, \
-                         strideB, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab); \
-    else \
-      hipLaunchKernelGGL((bgemm_x3_kernel<NNV, FOLDV, 64>), grid, dim3(kThreads), 0, st, A, Bm, out, rows, cols, K, strideA, \
-                         strideB, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab); \
+    if (tm == 128) { if (low) HECKA_BX3_(NNV, FOLDV, 128, true); else HECKA_BX3_(NNV, FOLDV, 128, false); } \
+    else { if (low) HECKA_BX3_(NNV, FOLDV, 64, true); else HECKA_BX3_(NNV, FOLDV, 64, false); } \
   } while (0)
   if (nn) { if (fold) HECKA_BX3(true, true); else HECKA_BX3(true, false); }
   else { if (fold) HECKA_BX3(false, true); else HECKA_BX3(false, false); }
 #undef HECKA_BX3
+#undef HECKA_BX3_
   if (int rc = check_launch("bgemm_x3")) return rc;
   if (ns > 1) {
     const long long n = slab;
@@ -4557,11 +4613,13 @@ int hecka_conv_x3_strided_f32(const float* A, const float* X, float* Y, const in
                                   alpha, amaxA, amaxB, amaxB_stride, stream);
 }
 
-int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
-                             long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
-                             int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
-                             const float* amaxB, int amaxB_stride, void* stream) {
+static int conv_x3_impl(bool tap, const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                        long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                        int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                        const float* amaxB, int amaxB_stride, void* stream) {
   clear_error();
+  if (tap && (Cin % kX6BK || (reinterpret_cast<uintptr_t>(tab) & 15)))
+    return fail(HECKA_EINVAL, "conv_x3 (tap-major): needs Cin %% 16 == 0 and a 16-byte aligned table%s");
   if (!A || !X || !Y || !tab || !amaxA || !amaxB) return fail(HECKA_EINVAL, "conv_x3: null pointer%s");
   if (esh <= 0 || esw <= 0 || eoh < 0 || eow < 0 || (long long)(Ho - 1) * esh + eoh >= OH || (long long)(Wo - 1) * esw + eow >= OW ||
       (long long)N * rows * OH * OW >= (1ll << 31))
@@ -4576,15 +4634,38 @@ int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int
   const int tilesM = rows / tm, tilesN = (int)((long long)N * Ho * Wo / 128);
   dim3 grid((unsigned)((long long)batch * tilesM * tilesN));
   hipStream_t st = (hipStream_t)stream;
-  const int2* t2 = reinterpret_cast<const int2*>(tab);
+  const void* t2 = tab;
   const bool fold = K > 1024;
+  const bool low = config().layer_products != 1;
+#define HECKA_CX3_(FOLDV, TMV, LOWV, TAPV) \
+  hipLaunchKernelGGL((conv_x3_kernel<FOLDV, TMV, LOWV, TAPV>), grid, dim3(kThreads), 0, st, A, X, Y, t2, rows, K, strideA, strideX, \
+                     N, Cin, H, W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, Ho, Wo, sh, sw, pl)
 #define HECKA_CX3(FOLDV, TMV) \
-  hipLaunchKernelGGL((conv_x3_kernel<FOLDV, TMV>), grid, dim3(kThreads), 0, st, A, X, Y, t2, rows, K, strideA, strideX, N, Cin, H, \
-                     W, amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, Ho, Wo, sh, sw, pl)
+  do { \
+    if (tap) { if (low) HECKA_CX3_(FOLDV, TMV, true, true); else HECKA_CX3_(FOLDV, TMV, false, true); } \
+    else { if (low) HECKA_CX3_(FOLDV, TMV, true, false); else HECKA_CX3_(FOLDV, TMV, false, false); } \
+  } while (0)
   if (tm == 128) { if (fold) HECKA_CX3(true, 128); else HECKA_CX3(false, 128); }
   else { if (fold) HECKA_CX3(true, 64); else HECKA_CX3(false, 64); }
 #undef HECKA_CX3
+#undef HECKA_CX3_
   return check_launch("conv_x3");
+}
+
+int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                             long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                             int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                             const float* amaxB, int amaxB_stride, void* stream) {
+  return conv_x3_impl(false, A, X, Y, tab, batch, rows, K, strideA, strideX, N, Cin, H, W, Ho, Wo, sh, sw, OH, OW, esh, esw, eoh,
+                      eow, alpha, amaxA, amaxB, amaxB_stride, stream);
+}
+
+int hecka_conv_x3_tapmajor_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                               long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                               int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                               const float* amaxB, int amaxB_stride, void* stream) {
+  return conv_x3_impl(true, A, X, Y, tab, batch, rows, K, strideA, strideX, N, Cin, H, W, Ho, Wo, sh, sw, OH, OW, esh, esw, eoh,
+                      eow, alpha, amaxA, amaxB, amaxB_stride, stream);
 }
 
 int hecka_conv_x3_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
@@ -4598,7 +4679,18 @@ static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
   const long long tiles = (long long)batch * (O / (O % 128 ? 64 : 128)) * (Rp / 128);
   long long want = (1024 + tiles - 1) / tiles, maxs = Q / 1024;
   if (want > maxs) want = maxs;
-  return want >= 2 ? (int)want : 1;
+  if (want < 2) return 1;
+  // two workgroups per CU: of the split counts around `want`, take the one whose grid fills its last scheduling round
+  // best (90 tiles x 12 = 1080 workgroups are three rounds of 512 slots, the third a tenth full; x 11 = 990 are two)
+  const long long slots = 2ll * device_cus();
+  long long best = want;
+  double best_eff = 0.0;
+  for (long long ns = std::max(2ll, want - want / 4); ns <= std::min(maxs, want + (want + 1) / 2); ++ns) {
+    const long long g = tiles * ns, rounds = (g + slots - 1) / slots;
+    const double eff = (double)g / (double)(rounds * slots);
+    if (eff > best_eff + 0.04) { best_eff = eff; best = ns; }   // (more splits = more slabs to reduce: only for a clear gain)
+  }
+  return (int)best;
 }
 
 int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo) {
@@ -4645,12 +4737,13 @@ int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, 
   float* out = ns > 1 ? (float*)ws : dW;
   const long long slab = (long long)batch * O * Rp;
   const int2* t2 = reinterpret_cast<const int2*>(tab);
-  if (tm == 128)
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
-                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw);
-  else
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, amaxA,
-                       amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw);
+  const bool low = config().layer_products != 1;
+#define HECKA_WX3(TMV, LOWV) \
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<TMV, LOWV>), grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, \
+                     amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw)
+  if (tm == 128) { if (low) HECKA_WX3(128, true); else HECKA_WX3(128, false); }
+  else { if (low) HECKA_WX3(64, true); else HECKA_WX3(64, false); }
+#undef HECKA_WX3
   if (int rc = check_launch("conv_wgrad_x3")) return rc;
   if (ns > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)slab,

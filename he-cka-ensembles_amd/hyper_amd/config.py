@@ -24,6 +24,7 @@ class _Knobs(object):
         self.conv_implicit = on('HECKA_CONV_IMPLICIT')    # implicit-GEMM convolutions
         self.conv_x3 = on('HECKA_CONV_X3')                # convolution / linear GEMMs on the fp16-split tile
         self.conv_direct = on('HECKA_CONV_DIRECT')        # few-channel direct convolution
+        self.conv_tapmajor = on('HECKA_CONV_TAPMAJOR')    # implicit convolutions with K ordered (tap, channel) where 16 | C
         self.conv_keep_cols_gb = float(env('HECKA_CONV_KEEP_COLS_GB', '8'))
         self.bn_fuse = on('HECKA_BN_FUSE')                # norm + residual + relu in one launch
         self.sampler_torch = set(filter(None, env('HECKA_SAMPLER_TORCH', '').split(',')))

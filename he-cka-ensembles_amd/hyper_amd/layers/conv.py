@@ -69,6 +69,26 @@ def _conv_tab(Cin, H, W, kh, kw, ph, pw, device, rows=None):
     return _TABS[key]
 
 
+def _tap_tab(Cin, H, W, taps, device):
+    """Table of the TAP-MAJOR implicit GEMM (hecka_conv_x3_tapmajor_f32): K ordered (tap, channel), one entry per k-tile of
+    16 channels = (byte offset of the tile's first channel, byte offset of the tap, di, dj), plus one entry of padding (the
+    kernel fetches one entry ahead).  taps: [(di, dj)] in the order of the weight matrix's K axis."""
+    key = ('tap', Cin, H, W, tuple(taps), str(device))
+    if key not in _TABS:
+        rows = [(cb * 16 * H * W * 4, (di * W + dj) * 4, di, dj) for di, dj in taps for cb in range(Cin // 16)]
+        rows.append((0, 0, -30000, -30000))
+        tab = (np.asarray(rows, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        if len(_TABS) > 256:
+            _TABS.clear()
+        _TABS[key] = torch.from_numpy(tab).contiguous().to(device)
+    return _TABS[key]
+
+
+def _tapmajor(Cin):
+    """K ordered (tap, channel) - one range check per k-tile instead of one per gathered element: 16 | Cin."""
+    return knobs.conv_tapmajor and Cin % 16 == 0
+
+
 def _conv_x3_ok(geom, M, rows, K, N, Cin, H, W):
     """The implicit-GEMM convolution with the output as large as the input (unit stride, 'same' padding): the forward of
     most layers and every input gradient that runs as a convolution of dy with the rotated weights."""
@@ -86,15 +106,17 @@ def _conv_x3_fwd_ok(geom, M, rows, K, N, Cin, H, W, Ho, Wo):
             and bool(_lib.lib().hecka_conv_x3_strided_eligible(M, rows, K, N, Cin, H, W, Ho, Wo)))
 
 
-def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride, out_hw=None, stride=(1, 1)):
+def _conv_x3(A, X, M, rows, K, sX, N, Cin, H, W, tab, alpha, amaxA, amaxB, amaxB_stride, out_hw=None, stride=(1, 1),
+             tapmajor=False):
     """Y [M,N,rows,Ho,Wo] = alpha * implicit-GEMM convolution of X [M|1,N,Cin,H,W] with A [M,rows,K] (see include/hecka.h);
-    out_hw / stride default to the same-size unit-stride case."""
+    out_hw / stride default to the same-size unit-stride case.  tapmajor: K ordered (tap, channel), tab from _tap_tab."""
     Ho, Wo = out_hw if out_hw is not None else (H, W)
     Y = torch.empty((M, N, rows, Ho, Wo), device=X.device, dtype=torch.float32)
-    _lib.check(_lib.lib().hecka_conv_x3_strided_f32(A.data_ptr(), X.data_ptr(), Y.data_ptr(), tab.data_ptr(), M, rows, K, rows * K,
-                                                    sX, N, Cin, H, W, Ho, Wo, int(stride[0]), int(stride[1]), float(alpha),
-                                                    amaxA.data_ptr(), amaxB.data_ptr(), int(amaxB_stride),
-                                                    torch.cuda.current_stream().cuda_stream), 'conv_x3')
+    L = _lib.lib()
+    fn = L.hecka_conv_x3_tapmajor_f32 if tapmajor else L.hecka_conv_x3_placed_f32
+    _lib.check(fn(A.data_ptr(), X.data_ptr(), Y.data_ptr(), tab.data_ptr(), M, rows, K, rows * K, sX, N, Cin, H, W, Ho, Wo,
+                  int(stride[0]), int(stride[1]), Ho, Wo, 1, 1, 0, 0, float(alpha), amaxA.data_ptr(), amaxB.data_ptr(),
+                  int(amaxB_stride), torch.cuda.current_stream().cuda_stream), 'conv_x3')
     return Y
 
 
@@ -135,25 +157,31 @@ def _dgrad_s2(W, dy, geom, N, H, Wd, Ho, Wo, scale, wmax, dymax):
     classes = _dgrad_s2_classes(geom, H, Wd)
     full = all(I and J and U and V for _, _, I, J, _, _, U, V in classes)
     dx = (torch.empty if full else torch.zeros)((M, N, C, H, Wd), device=dy.device, dtype=torch.float32)
-    Wp = W.permute(0, 2, 1, 3, 4)                                    # [M, C, O, kh, kw]
+    tap = _tapmajor(O)
+    Wp = W.permute(0, 2, 3, 4, 1) if tap else W.permute(0, 2, 1, 3, 4)      # [M, C, kh, kw, O] | [M, C, O, kh, kw]
     L = _lib.lib()
+    fn = L.hecka_conv_x3_tapmajor_f32 if tap else L.hecka_conv_x3_placed_f32
     for a, b, I, J, di, dj, U, V in classes:
         if not I or not J or U == 0 or V == 0:
             continue
         K = O * len(I) * len(J)
-        A = Wp[:, :, :, I][:, :, :, :, J].reshape(M, C, K).contiguous()
-        key = ('dgrad2', O, Ho, Wo, tuple(di), tuple(dj), str(dy.device))
-        if key not in _TABS:
-            o = torch.arange(O, dtype=torch.int64).view(O, 1, 1)
-            ti = torch.tensor(di, dtype=torch.int64).view(1, -1, 1)
-            tj = torch.tensor(dj, dtype=torch.int64).view(1, 1, -1)
-            off = ((o * Ho + ti) * Wo + tj).reshape(-1)
-            pk = ((ti << 16) | (tj & 0xffff)).expand(O, -1, -1).reshape(-1)
-            _TABS[key] = torch.stack([off, pk], dim=1).to(torch.int32).contiguous().to(dy.device)
-        _lib.check(L.hecka_conv_x3_placed_f32(
-            A.data_ptr(), dy.data_ptr(), dx.data_ptr(), _TABS[key].data_ptr(), M, C, K, C * K, N * O * Ho * Wo, N, O, Ho, Wo,
-            U, V, 1, 1, H, Wd, 2, 2, a, b, float(scale), wmax.data_ptr(), dymax.data_ptr(), 1,
-            torch.cuda.current_stream().cuda_stream), 'conv_x3_placed')
+        if tap:
+            A = Wp[:, :, I][:, :, :, J].reshape(M, C, K).contiguous()
+            tab = _tap_tab(O, Ho, Wo, [(ti, tj) for ti in di for tj in dj], dy.device)
+        else:
+            A = Wp[:, :, :, I][:, :, :, :, J].reshape(M, C, K).contiguous()
+            key = ('dgrad2', O, Ho, Wo, tuple(di), tuple(dj), str(dy.device))
+            if key not in _TABS:
+                o = torch.arange(O, dtype=torch.int64).view(O, 1, 1)
+                ti = torch.tensor(di, dtype=torch.int64).view(1, -1, 1)
+                tj = torch.tensor(dj, dtype=torch.int64).view(1, 1, -1)
+                off = ((o * Ho + ti) * Wo + tj).reshape(-1)
+                pk = ((ti << 16) | (tj & 0xffff)).expand(O, -1, -1).reshape(-1)
+                _TABS[key] = torch.stack([off, pk], dim=1).to(torch.int32).contiguous().to(dy.device)
+            tab = _TABS[key]
+        _lib.check(fn(A.data_ptr(), dy.data_ptr(), dx.data_ptr(), tab.data_ptr(), M, C, K, C * K, N * O * Ho * Wo, N, O, Ho, Wo,
+                      U, V, 1, 1, H, Wd, 2, 2, a, b, float(scale), wmax.data_ptr(), dymax.data_ptr(), 1,
+                      torch.cuda.current_stream().cuda_stream), 'conv_x3_placed')
     return dx
 
 
@@ -212,14 +240,19 @@ class BatchedConv2d(torch.autograd.Function):
             return y
         if not has_bias and _conv_x3_fwd_ok(geom, M, O, K, N, C, H, Wd, Ho, Wo):
             # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
-            Wf = W.reshape(M, O, K).contiguous()
+            tap = _tapmajor(C)
+            if tap:      # K ordered (tap, channel): one copy of the weights per step, no range check per gathered element
+                Wf = W.permute(0, 1, 3, 4, 2).reshape(M, O, K).contiguous()
+                tab = _tap_tab(C, H, Wd, [(i - geom[4], j - geom[5]) for i in range(kh) for j in range(kw)], x5.device)
+            else:
+                Wf = W.reshape(M, O, K).contiguous()
+                tab = _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device)
             xmax = (cached_absmax(x, Mx) if not shared else None)
             if xmax is None:
                 xmax = _absmax_rows(x5.reshape(Mx, -1), Mx)
             wmax = _absmax_rows(Wf.reshape(M, -1), M)
-            y = _conv_x3(Wf, x5, M, O, K, 0 if shared else N * C * H * Wd, N, C, H, Wd,
-                         _conv_tab(C, H, Wd, kh, kw, geom[4], geom[5], x5.device), scale, wmax, xmax, 0 if shared else 1,
-                         (Ho, Wo), (geom[2], geom[3]))
+            y = _conv_x3(Wf, x5, M, O, K, 0 if shared else N * C * H * Wd, N, C, H, Wd, tab, scale, wmax, xmax,
+                         0 if shared else 1, (Ho, Wo), (geom[2], geom[3]), tap)
             ctx.save_for_backward(x5, W, None, xmax, wmax)
             ctx.cfg = (scale, bias_scale, geom, shared, has_bias, (N, Ho, Wo))
             return y
@@ -285,9 +318,15 @@ class BatchedConv2d(torch.autograd.Function):
         H, Wd = x5.shape[3], x5.shape[4]
         if ctx.needs_input_grad[0] and dymax is not None and _conv_x3_ok(geom, M, C, O * kh * kw, N, O, H, Wd):
             # input gradient as an implicit-GEMM convolution of dy with the rotated weights: no dgrad patch matrix, no col2im
-            Wrot = W.flip(3, 4).transpose(1, 2).reshape(M, C, O * kh * kw).contiguous()
-            dx = _conv_x3(Wrot, dy, M, C, O * kh * kw, N * O * H * Wd, N, O, H, Wd,
-                          _conv_tab(O, H, Wd, kh, kw, kh - 1 - geom[4], kw - 1 - geom[5], dy.device), scale, wmax, dymax, 1)
+            tap = _tapmajor(O)
+            if tap:
+                Wrot = W.flip(3, 4).permute(0, 2, 3, 4, 1).reshape(M, C, O * kh * kw).contiguous()
+                tab = _tap_tab(O, H, Wd, [(i - (kh - 1 - geom[4]), j - (kw - 1 - geom[5])) for i in range(kh) for j in range(kw)],
+                               dy.device)
+            else:
+                Wrot = W.flip(3, 4).transpose(1, 2).reshape(M, C, O * kh * kw).contiguous()
+                tab = _conv_tab(O, H, Wd, kh, kw, kh - 1 - geom[4], kw - 1 - geom[5], dy.device)
+            dx = _conv_x3(Wrot, dy, M, C, O * kh * kw, N * O * H * Wd, N, O, H, Wd, tab, scale, wmax, dymax, 1, tapmajor=tap)
             dx = dx.sum(0) if shared else dx
         if (ctx.needs_input_grad[0] and dx is None and dymax is not None and not has_bias
                 and _dgrad_s2_ok(geom, M, C, O, N, H, Wd, Ho, Wo)):

@@ -51,6 +51,29 @@ def gemm_mode(mode):
         _mode_tls.mode = prev
 
 
+def set_layer_products(n):
+    """Products per multiply of the LAYER GEMMs / convolutions on the fp16-split tile (hecka_set_layer_products): 3 = fp32-grade
+    (default), 1 = 16-bit compute (operands rounded to fp16 after their power-of-two scale, fp32 accumulation).  Process-wide
+    (the library's setting, also read from HECKA_LAYER_PRODUCTS); the loss path is not touched.  Returns the previous value."""
+    old = _lib.lib().hecka_set_layer_products(int(n))
+    if old < 0:
+        raise ValueError('layer products must be 3 (fp32-grade) or 1 (16-bit compute)')
+    return old
+
+
+def get_layer_products():
+    return int(_lib.lib().hecka_get_layer_products())
+
+
+@contextlib.contextmanager
+def layer_products(n):
+    prev = set_layer_products(n)
+    try:
+        yield
+    finally:
+        set_layer_products(prev)
+
+
 def mode_aware(cls):
     """Class decorator for autograd Functions that launch the large GEMMs: backward runs on autograd's thread, so the
     node remembers the GEMM mode its forward ran under and re-enters it."""

@@ -32,6 +32,14 @@ const char* hecka_last_error(void);
 /* The library reads its (few, optional) HECKA_* environment knobs once, at load time - never on the call path;
  * hecka_config_reload() re-reads them (tests that switch a knob inside one process).  INTEGRATION.md 6 lists them. */
 void hecka_config_reload(void);
+/* Products per multiply of the LAYER GEMMs and convolutions on the fp16-split tile (hecka_bgemm_x3_f32, hecka_conv_*x3*_f32);
+ * the loss path is not touched.  3 (default): x 2^e = h + l, products hh + hl + lh - fp32-grade.  1: hh only - the operands
+ * (fp32 in HBM) are rounded to fp16 after their power-of-two scale, accumulation stays fp32: a 16-bit COMPUTE mode (11
+ * significand bits, more than bf16's 8).  No counterpart in the reference, which is fp32-only: results
+ * equal the fp64 product of the rounded operands (tests/test_gpu_parity.py), parity with the reference is unpinned.
+ * Process-wide; returns the previous value, -1 for a value other than 1 or 3.  HECKA_LAYER_PRODUCTS sets the initial one. */
+int hecka_set_layer_products(int n);
+int hecka_get_layer_products(void);
 
 /* Arithmetic of the two large GEMMs - the `gemm_mode` argument of hecka_gram_center_*, hecka_gram_bwd_*.  No counterpart
  * in the reference (torch.bmm picks its own algorithm).  It is a per-call argument: the library holds no process-wide
@@ -331,6 +339,16 @@ int hecka_conv_x3_placed_f32(const float* A, const float* X, float* Y, const int
                              long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
                              int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
                              const float* amaxB, int amaxB_stride, void* stream);
+/* hecka_conv_x3_placed_f32 with the K axis ordered (tap, channel) instead of (channel, tap): A [batch,rows,T Cin] with column
+ * (t, c), Cin % 16 == 0, so a k-tile of 16 holds 16 channels of ONE tap and whether the tap falls inside the image is decided
+ * once per k-tile and thread (the (c, i, j) order pays a table lookup and a range check per gathered element: the
+ * gather, not the MFMAs, bounded those launches).  tab [T Cin / 16 + 1][4] int32 per k-tile: { byte offset of the tile's
+ * first channel = c0 H W 4, byte offset of the tap = (di W + dj) 4, di, dj }; the last entry is padding (the kernel fetches one
+ * entry ahead), 16-byte aligned.  Everything else as hecka_conv_x3_placed_f32 (dense output: OH = Ho, OW = Wo, 1, 1, 0, 0). */
+int hecka_conv_x3_tapmajor_f32(const float* A, const float* X, float* Y, const int* tab, int batch, int rows, int K,
+                               long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
+                               int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
+                               const float* amaxB, int amaxB_stride, void* stream);
 int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 size_t hecka_conv_wgrad_x3_strided_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,

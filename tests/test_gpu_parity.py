@@ -1037,6 +1037,61 @@ def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, C, monkeypatch):
         assert _relerr(res[mode][2].numpy(), Wd.grad.numpy()) <= RTOL, mode
 
 
+def _round_f16_scaled(t, amax):
+    """What the single-product tile multiplies: t * 2^k rounded to fp16 (nearest even), 2^k the power-of-two scale of
+    pow2_scale(amax, 14) - amax 2^k < 2^14 -, as fp64 with the scale undone.  amax per leading index of t."""
+    _, e = torch.frexp(amax.double().cpu())
+    s = torch.pow(torch.tensor(2.0, dtype=torch.float64), (14 - e).double()).view(-1, *([1] * (t.ndim - 1)))
+    return (t.cpu().double() * s).float().half().double() / s
+
+
+@pytest.mark.parametrize('stride,C,O', [(1, 64, 128), (2, 128, 64)])
+def test_single_product_layer_mode_is_the_fp64_product_of_fp16_rounded_operands(stride, C, O):
+    """ops.layer_products(1) - the 16-bit COMPUTE mode of the layer GEMMs (hecka_set_layer_products; no counterpart in the
+    fp32-only reference: parity with it is unpinned).  Pinned instead to what it claims to be: each operand rounded to fp16 after
+    its per-member power-of-two scale, exact products, fp32 accumulation - so forward, input gradient and weight gradient of a
+    convolution equal the fp64 convolution of the ROUNDED operands to accumulation error, and differ from the unrounded one
+    by about 2^-12.  Tap-major forward / dgrad (stride 1), the parity-class dgrad (stride 2), both weight gradients, and the
+    batched GEMM of the Linear layers."""
+    import torch.nn.functional as F
+    from hyper_amd import ops
+    from hyper_amd.layers.conv import BatchedConv2d
+    from hyper_amd.layers.linear import _bgemm_x3, _absmax_rows
+    dev = _dev()
+    torch.manual_seed(23)
+    M, N, HW = 2, 16, 16
+    x = torch.randn(M, N, C, HW, HW, device=dev)
+    W = torch.randn(M, O, C, 3, 3, device=dev) * 0.05
+    up = torch.randn(M, N, O, HW // stride, HW // stride, device=dev)
+    geom = (3, 3, stride, stride, 1, 1, 1, 1)
+    assert ops.get_layer_products() == 3
+    with ops.layer_products(1):
+        assert ops.get_layer_products() == 1
+        xx, WW = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        y = BatchedConv2d.apply(xx, WW, None, 0.7, 1.0, geom)
+        (y * up).sum().backward()
+        A, Bm = torch.randn(M, 128, 256, device=dev), torch.randn(M, 256, 128, device=dev)
+        amA, amB = _absmax_rows(A.view(M, -1), M), _absmax_rows(Bm.view(M, -1), M)
+        prod = _bgemm_x3(A, Bm, M, 128, 128, 256, 128 * 256, 256 * 128, True, 1.0, amA, amB, 1)
+    assert ops.get_layer_products() == 3
+    amax = lambda t: t.reshape(M, -1).abs().amax(1)
+    xr, Wr, ur = _round_f16_scaled(x, amax(x)), _round_f16_scaled(W, amax(W)), _round_f16_scaled(up, amax(up))
+    conv = lambda a, w: torch.stack([F.conv2d(a[m], 0.7 * w[m], None, stride, 1) for m in range(M)])
+    y_ref = conv(xr, Wr)
+    xl = x.cpu().double().requires_grad_(True)
+    (conv(xl, Wr) * ur).sum().backward()
+    Wl = W.cpu().double().requires_grad_(True)
+    (conv(xr, Wl) * ur).sum().backward()
+    assert _relerr(y.detach().cpu().double().numpy(), y_ref.numpy()) <= RTOL
+    assert _relerr(xx.grad.cpu().double().numpy(), xl.grad.numpy()) <= RTOL
+    assert _relerr(WW.grad.cpu().double().numpy(), Wl.grad.numpy()) <= RTOL
+    exact = conv(x.cpu().double(), W.cpu().double())
+    dev16 = _relerr(y.detach().cpu().double().numpy(), exact.numpy())
+    assert 1e-5 < dev16 < 2e-3, dev16            # it IS a 16-bit product (and not a worse one)
+    p_ref = _round_f16_scaled(A, amA) @ _round_f16_scaled(Bm, amB)
+    assert _relerr(prod.cpu().double().numpy(), p_ref.numpy()) <= RTOL
+
+
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
 def test_multi_gram_split_k_matches_unsplit(dtype, monkeypatch):
     """Few workgroups over deep layers (here 8 members x 1 tile x 3 layers): the multi-layer Gram launch splits layers

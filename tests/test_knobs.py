@@ -102,17 +102,19 @@ def test_streamed_dx_launch_is_bit_equal_to_a_workgroup_per_tile(M, B, Ps, grid,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('knob,value', [('HECKA_CONV_IMPLICIT', '0'), ('HECKA_CONV_KEEP_COLS_GB', '0')])
-def test_conv_knob_alternative_matches_default(knob, value, monkeypatch):
-    """Implicit-GEMM convolution off (explicit im2col / col2im for every conv) / gathered patches never kept for backward."""
+@pytest.mark.parametrize('knob,value,stride', [('HECKA_CONV_IMPLICIT', '0', 1), ('HECKA_CONV_KEEP_COLS_GB', '0', 1),
+                                               ('HECKA_CONV_TAPMAJOR', '0', 1), ('HECKA_CONV_TAPMAJOR', '0', 2)])
+def test_conv_knob_alternative_matches_default(knob, value, stride, monkeypatch):
+    """Implicit-GEMM convolution off (explicit im2col / col2im for every conv) / gathered patches never kept for backward /
+    the implicit GEMMs with K ordered (channel, tap) - a range check per gathered element - instead of (tap, channel)."""
     from hyper_amd.layers.conv import BatchedConv2d
     dev = torch.device('cuda:0')
     torch.manual_seed(5)
     M, N, C, HW = 2, 16, 128, 16
     x = torch.randn(M, N, C, HW, HW, device=dev)
     W = torch.randn(M, C, C, 3, 3, device=dev) * 0.05
-    up = torch.randn(M, N, C, HW, HW, device=dev)
-    geom = (3, 3, 1, 1, 1, 1, 1, 1)
+    up = torch.randn(M, N, C, HW // stride, HW // stride, device=dev)
+    geom = (3, 3, stride, stride, 1, 1, 1, 1)
     res = []
     for setting in (None, value):
         if setting is not None:
