@@ -2652,6 +2652,50 @@ __global__ __launch_bounds__(256) void col2im_s1_kernel(const float* __restrict_
 }
 
 
+// Weight layouts of the tap-major implicit GEMMs, from W [M, O, C, T] (T = kh kw taps; the reference's parameter layout):
+//   forward   Wf [M, O, T, C]:   Wf[m][o][t][c] = W[m][o][c][t]            - a [C, T] -> [T, C] transpose per (m, o)
+//   dgrad     Wr [M, C, T, O]:   Wr[m][c][t][o] = W[m][o][c][T - 1 - t]    - an [O, C T] -> [C T, O] transpose per member, taps flipped
+// (torch's strided copy moved these at about 0.6 TB/s: 0.7 ms of a 34.6 ms CIFAR ResNet18 step.)
+__global__ __launch_bounds__(256) void conv_weights_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int T,
+                                                               int chunks) {
+  extern __shared__ float wbuf[];
+  const int CT = C * T;
+  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const float* src = in + (size_t)ch * CT;
+    float* dst = out + (size_t)ch * CT;
+    for (int i = threadIdx.x; i < CT; i += 256) wbuf[i] = src[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT; i += 256) {
+      const int t = i / C, c = i - t * C;
+      dst[i] = wbuf[c * T + t];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_weights_rot_kernel(const float* __restrict__ in, float* __restrict__ out, int O, int C,
+                                                               int T) {
+  __shared__ float tile[32][33];
+  const int R = C * T, m = blockIdx.z;
+  const int r0 = blockIdx.x * 32, o0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = in + (size_t)m * O * R;
+  float* dst = out + (size_t)m * O * R;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = o0 + ty + 8 * k, r = r0 + tx;
+    tile[ty + 8 * k][tx] = (o < O && r < R) ? src[(size_t)o * R + r] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, o = o0 + tx;
+    if (r < R && o < O) {
+      const int c = r / T, t = r - c * T;
+      dst[(size_t)(c * T + (T - 1 - t)) * O + o] = tile[tx][ty + 8 * k];
+    }
+  }
+}
+
 // Stride 2 on both axes, no dilation, W % 4 == 0 (the stage transitions of a ResNet: 3 x 3 / pad 1 and the 1 x 1 shortcut): four
 // adjacent pixels per thread as above.  A tap row i reaches image row h only when h + ph - i is even, and of the four
 // pixels exactly the two with the parity of j + pw see tap column j - at two CONSECUTIVE output columns: every patch
@@ -4791,6 +4835,24 @@ int hecka_im2col_f32(const float* x, int Mx, int N, int C, int H, int W, int kh,
     hipLaunchKernelGGL(im2col_kernel<1>, dim3((unsigned)((Q + 255) / 256), R, Mx), dim3(256), 0, (hipStream_t)stream, x, g,
                        ones_row, cols);
   return check_launch("im2col");
+}
+
+int hecka_conv_weights_tapmajor_f32(const float* W, int M, int O, int C, int T, int rot, float* out, void* stream) {
+  clear_error();
+  if (!W || !out || W == out) return fail(HECKA_EINVAL, "conv_weights_tapmajor: null or aliased pointer%s");
+  if (M <= 0 || O <= 0 || C <= 0 || T <= 0 || (long long)M * O * C * T >= (1ll << 31) || (long long)C * T * 4 > 64 * 1024 ||
+      M > 65535)
+    return fail(HECKA_EINVAL, "conv_weights_tapmajor: size out of range (C T <= 16384)%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (rot) {
+    const int R = C * T;
+    hipLaunchKernelGGL(conv_weights_rot_kernel, dim3((R + 31) / 32, (O + 31) / 32, M), dim3(256), 0, st, W, out, O, C, T);
+  } else {
+    const int chunks = M * O;
+    hipLaunchKernelGGL(conv_weights_fwd_kernel, dim3(std::min(chunks, 8 * device_cus())), dim3(256), (size_t)C * T * 4, st, W, out,
+                       C, T, chunks);
+  }
+  return check_launch("conv_weights_tapmajor");
 }
 
 int hecka_col2im_f32(const float* dcols, int M, int N, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,

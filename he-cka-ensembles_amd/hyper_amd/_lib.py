@@ -75,6 +75,7 @@ SIGNATURES = {
     'hecka_conv_x3_strided_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp]),
     'hecka_conv_x3_placed_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp]),
     'hecka_conv_x3_tapmajor_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _i, _vp]),
+    'hecka_conv_weights_tapmajor_f32': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'hecka_set_layer_products': (_i, [_i]),
     'hecka_get_layer_products': (_i, []),
     'hecka_conv_wgrad_x3_strided_eligible': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

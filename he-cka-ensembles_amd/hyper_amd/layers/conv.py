@@ -84,6 +84,20 @@ def _tap_tab(Cin, H, W, taps, device):
     return _TABS[key]
 
 
+def _tap_weights(W, rot):
+    """W [M,O,C,kh,kw] -> [M,O,kh kw C] (forward) or the rotated [M,C,kh kw O] (input gradient): the A operand of the tap-major
+    implicit GEMM (hecka_conv_weights_tapmajor_f32)."""
+    M, O, C, kh, kw = W.shape
+    if C * kh * kw > 16384:
+        Wt = W.flip(3, 4).permute(0, 2, 3, 4, 1) if rot else W.permute(0, 1, 3, 4, 2)
+        return Wt.reshape(M, C if rot else O, -1).contiguous()
+    Wc = W.detach().contiguous()
+    out = torch.empty((M, C, kh * kw * O) if rot else (M, O, kh * kw * C), device=W.device, dtype=torch.float32)
+    _lib.check(_lib.lib().hecka_conv_weights_tapmajor_f32(Wc.data_ptr(), M, O, C, kh * kw, int(rot), out.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream), 'conv_weights_tapmajor')
+    return out
+
+
 def _tapmajor(Cin):
     """K ordered (tap, channel) - one range check per k-tile instead of one per gathered element: 16 | Cin."""
     return knobs.conv_tapmajor and Cin % 16 == 0
@@ -242,7 +256,7 @@ class BatchedConv2d(torch.autograd.Function):
             # implicit GEMM: no patch matrix in forward (the weight gradient gathers it in backward), y written as NCHW
             tap = _tapmajor(C)
             if tap:      # K ordered (tap, channel): one copy of the weights per step, no range check per gathered element
-                Wf = W.permute(0, 1, 3, 4, 2).reshape(M, O, K).contiguous()
+                Wf = _tap_weights(W, False)
                 tab = _tap_tab(C, H, Wd, [(i - geom[4], j - geom[5]) for i in range(kh) for j in range(kw)], x5.device)
             else:
                 Wf = W.reshape(M, O, K).contiguous()
@@ -320,7 +334,7 @@ class BatchedConv2d(torch.autograd.Function):
             # input gradient as an implicit-GEMM convolution of dy with the rotated weights: no dgrad patch matrix, no col2im
             tap = _tapmajor(O)
             if tap:
-                Wrot = W.flip(3, 4).permute(0, 2, 3, 4, 1).reshape(M, C, O * kh * kw).contiguous()
+                Wrot = _tap_weights(W, True)
                 tab = _tap_tab(O, H, Wd, [(i - (kh - 1 - geom[4]), j - (kw - 1 - geom[5])) for i in range(kh) for j in range(kw)],
                                dy.device)
             else:

@@ -349,6 +349,10 @@ int hecka_conv_x3_tapmajor_f32(const float* A, const float* X, float* Y, const i
                                long long strideA, long long strideX, int N, int Cin, int H, int W, int Ho, int Wo, int sh, int sw,
                                int OH, int OW, int esh, int esw, int eoh, int eow, float alpha, const float* amaxA,
                                const float* amaxB, int amaxB_stride, void* stream);
+/* The weight operands of hecka_conv_x3_tapmajor_f32 from W [M,O,C,T] (T = kh kw; the parameter layout of hyper/layers/conv.py:
+ * 434-502): rot = 0 -> out [M,O,T,C] = W[m][o][c][t] (forward); rot = 1 -> out [M,C,T,O] = W[m][o][c][T-1-t] (input gradient:
+ * channels swapped, taps rotated by 180 degrees).  C T <= 16384, out != W. */
+int hecka_conv_weights_tapmajor_f32(const float* W, int M, int O, int C, int T, int rot, float* out, void* stream);
 int hecka_conv_wgrad_x3_strided_eligible(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 size_t hecka_conv_wgrad_x3_strided_workspace_bytes(int batch, int O, int Rp, int N, int C, int H, int W, int Ho, int Wo);
 int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, const int* tab, int batch, int O, int Rp,

@@ -1037,6 +1037,18 @@ def test_conv_x3_gemms_match_fp64_conv(N, HW, shared, C, monkeypatch):
         assert _relerr(res[mode][2].numpy(), Wd.grad.numpy()) <= RTOL, mode
 
 
+@pytest.mark.parametrize('M,O,C,k', [(2, 64, 128, (3, 3)), (3, 40, 48, (1, 1)), (1, 130, 16, (5, 5)), (2, 32, 80, (2, 3))])
+def test_tapmajor_weight_layouts_equal_the_torch_permutes(M, O, C, k):
+    """hecka_conv_weights_tapmajor_f32: W [M,O,C,kh,kw] -> [M,O,(kh kw),C] (forward operand) and the rotated [M,C,(kh kw),O]
+    (input-gradient operand) - bit-equal to permute / flip + permute."""
+    from hyper_amd.layers.conv import _tap_weights
+    dev = _dev()
+    torch.manual_seed(3)
+    W = torch.randn(M, O, C, *k, device=dev)
+    assert torch.equal(_tap_weights(W, False), W.permute(0, 1, 3, 4, 2).reshape(M, O, -1))
+    assert torch.equal(_tap_weights(W, True), W.flip(3, 4).permute(0, 2, 3, 4, 1).reshape(M, C, -1))
+
+
 def _round_f16_scaled(t, amax):
     """What the single-product tile multiplies: t * 2^k rounded to fp16 (nearest even), 2^k the power-of-two scale of
     pow2_scale(amax, 14) - amax 2^k < 2^14 -, as fp64 with the scale undone.  amax per leading index of t."""
