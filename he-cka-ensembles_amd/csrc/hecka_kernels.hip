@@ -1310,6 +1310,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same for LARGE outputs (the split-K slabs of a layer's weight gradient: millions of elements, 4 - 20 slabs): four
+// consecutive outputs per thread, the slabs summed in order z = 0, 1, .. (fixed order: deterministic), every access a whole
+// 16-byte piece of a contiguous run - the kernel above spends a workgroup and a barrier on 16 outputs.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __restrict__ part, int nsplit, int n4,
+                                                                 float* __restrict__ S, float alpha) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+  f32x4 s = p[0];
+  for (int z = 1; z < nsplit; ++z) {
+    const f32x4 v = p[(size_t)z * n4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] *= alpha;
+  reinterpret_cast<f32x4*>(S)[i] = s;
+}
+
 // ------------------------------------------------------------------------------------------
 // (4) gamma = A cvec  (tiny)
 // ------------------------------------------------------------------------------------------
@@ -4559,7 +4578,11 @@ int hecka_bgemm_splitk_f32(const float* A, const float* Bm, float* C, int batch,
   if (nn) { if (vec) HECKA_BGEMMS(true, true); else HECKA_BGEMMS(true, false); }
   else    { if (vec) HECKA_BGEMMS(false, true); else HECKA_BGEMMS(false, false); }
 #undef HECKA_BGEMMS
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nsplit, (int)n, C, alpha);
+  if (n % 4 == 0 && n >= (1 << 16) && aligned16(part) && aligned16(C))
+    hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, part, nsplit, (int)(n / 4),
+                       C, alpha);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nsplit, (int)n, C, alpha);
   return check_launch("bgemm_splitk");
 }
 
@@ -4632,7 +4655,11 @@ int hecka_bgemm_x3_f32(const float* A, const float* Bm, float* C, int batch, int
   if (ns > 1) {
     const long long n = slab;
     if (n > 0x7fffffffLL) return fail(HECKA_EINVAL, "bgemm_x3: output too large for the split-K reduction%s");
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)n, C, alpha);
+    if (aligned16(ws))      // (n = batch rows cols with cols % 128 == 0: whole quads; C is 16-byte aligned - checked above)
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, ns,
+                         (int)(n / 4), C, alpha);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)n, C, alpha);
     return check_launch("bgemm_x3 (reduce)");
   }
   return HECKA_OK;
@@ -4790,8 +4817,13 @@ int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, 
 #undef HECKA_WX3
   if (int rc = check_launch("conv_wgrad_x3")) return rc;
   if (ns > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)slab,
-                       dW, alpha);
+    // (slab = batch O Rp with Rp % 128 == 0: whole quads; ws and dW 16-byte aligned - checked below / by the tile)
+    if (aligned16(ws) && aligned16(dW))
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((slab / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, ns,
+                         (int)(slab / 4), dW, alpha);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, (const float*)ws, ns, (int)slab,
+                         dW, alpha);
     return check_launch("conv_wgrad_x3 (reduce)");
   }
   return HECKA_OK;
