@@ -107,15 +107,24 @@ def train_rates(budget_s):
     out, t0 = {}, time.perf_counter()
     for key, name, kw in (('mnist_lenet_m5_b300', 'mnist', dict(graph=True, steps=60)),
                           ('toy_m30_b100', 'toy', dict(graph=True, steps=60)),
-                          ('cifar_rn18_m10_b128', 'cifar', dict(steps=8)),
+                          ('cifar_rn18_m10_b128', 'cifar', dict(steps=20, warmup=5)),
+                          # the same step with the layer GEMMs in the 16-bit COMPUTE mode (ops.layer_products(1): operands rounded to
+                          # fp16 after their power-of-two scale, fp32 accumulation and storage; the loss path untouched) - an extra
+                          # line, NOT the fp32 step above and not what the reference computes (it is fp32-only)
+                          ('cifar_rn18_m10_b128_16bit_compute', 'cifar', dict(steps=20, warmup=5, products=1)),
                           ('mnist_hyper_m128', 'hyper', dict(steps=10))):
         if time.perf_counter() - t0 > budget_s:
             out[key] = None
             continue
         try:
-            r = train_bench.run(name, warmup=3, **kw)
+            kw = dict(kw)
+            products = kw.pop('products', 3)
+            from hyper_amd import ops
+            with ops.layer_products(products):
+                r = train_bench.run(name, **dict(dict(warmup=3), **kw))
             out[key] = {'steps_per_s': r['steps_per_s'], 'ms_per_step': r['ms_per_step'],
-                        'mode': 'one HIP graph per step' if kw.get('graph') else 'eager'}
+                        'mode': ('one HIP graph per step' if kw.get('graph') else 'eager') +
+                                (', layer GEMMs with one fp16 product per multiply' if products == 1 else '')}
         except Exception as e:      # the headline line must survive a failure here
             out[key] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         torch.cuda.empty_cache()
