@@ -2906,6 +2906,7 @@ struct BnExtra {
   float* run_mean_upd;
   float* run_var_upd;
   float factor, unbias;
+  unsigned char* mask;   // (may be NULL) one byte per four outputs: bit e = y[4 i + e] > 0 - what the backward needs of y
 };
 struct BnPair { f32x4 d, v; };
 struct BnTriple { f32x4 d, v, y; };
@@ -2976,6 +2977,9 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
                for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
              }
              *reinterpret_cast<f32x4*>(y + o) = r;
+             if (ex.mask)
+               ex.mask[o >> 2] = (unsigned char)((r[0] > 0.f ? 1u : 0u) | (r[1] > 0.f ? 2u : 0u) | (r[2] > 0.f ? 4u : 0u) |
+                                                 (r[3] > 0.f ? 8u : 0u));
              amax = fmaxf(fmaxf(fmaxf(amax, fabsf(r[0])), fmaxf(fabsf(r[1]), fabsf(r[2]))), fabsf(r[3]));
            });
   if (ymax) {
@@ -2989,9 +2993,11 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ weight, int N, int C, long long S,
                                                                 int training, float* __restrict__ dx, float* __restrict__ dweight,
                                                                 float* __restrict__ dbias, const float* __restrict__ yout,
-                                                                float* __restrict__ dres, unsigned* __restrict__ dxmax, int wstride) {
+                                                                float* __restrict__ dres, unsigned* __restrict__ dxmax, int wstride,
+                                                                const unsigned char* __restrict__ mask) {
   // yout (the fused op's output; may be NULL): relu mask, the gradient reaching the normalisation is dy where yout > 0;
-  // dres (may be NULL) receives that masked gradient for the residual branch
+  // mask (may be NULL; instead of yout): the same as the forward's byte per four outputs - 1 / 16 of the bytes of yout in
+  // each of the two sweeps; dres (may be NULL) receives that masked gradient for the residual branch
   __shared__ double red[4];
   const int c = blockIdx.x, g = blockIdx.y;
   const long long cnt = (long long)N * S;
@@ -3003,12 +3009,18 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
     BnTriple p;
     p.d = *reinterpret_cast<const f32x4*>(dy + o);
     p.v = *reinterpret_cast<const f32x4*>(x + o);
-    p.y = yout ? *reinterpret_cast<const f32x4*>(yout + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+    if (mask) {
+      const unsigned b = mask[o >> 2];
+      p.y = f32x4{(float)(b & 1u), (float)((b >> 1) & 1u), (float)((b >> 2) & 1u), (float)((b >> 3) & 1u)};
+    } else {
+      p.y = yout ? *reinterpret_cast<const f32x4*>(yout + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
     return p;
   };
+  const bool masked = yout || mask;
   bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
     f32x4 d = p.d;
-    if (yout) {
+    if (masked) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = p.y[e] > 0.f ? d[e] : 0.f;
       if (dres) *reinterpret_cast<f32x4*>(dres + o) = d;
@@ -3029,7 +3041,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   float amax = 0.f;
   bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
     f32x4 d = p.d;
-    if (yout) {
+    if (masked) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = p.y[e] > 0.f ? d[e] : 0.f;
     }
@@ -4920,7 +4932,7 @@ int hecka_batchnorm_fwd_f32(const float* x, int G, int N, int C, long long S, co
   if (S % 4 == 0 && aligned16(x) && aligned16(y))
     hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                        run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, (const float*)nullptr, 0,
-                       (unsigned*)nullptr, BnExtra{C, nullptr, nullptr, 0.f, 0.f});
+                       (unsigned*)nullptr, BnExtra{C, nullptr, nullptr, 0.f, 0.f, nullptr});
   else
     hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                        run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var);
@@ -4935,7 +4947,8 @@ int hecka_batchnorm_bwd_f32(const float* dy, const float* x, const float* save_m
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_bwd: size out of range%s");
   if (S % 4 == 0 && aligned16(x) && aligned16(dy) && (!dx || aligned16(dx)))
     hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                       weight, N, C, S, training, dx, dweight, dbias, (const float*)nullptr, (float*)nullptr, (unsigned*)nullptr, C);
+                       weight, N, C, S, training, dx, dweight, dbias, (const float*)nullptr, (float*)nullptr, (unsigned*)nullptr, C,
+                       (const unsigned char*)nullptr);
   else
     hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
                        weight, N, C, S, training, dx, dweight, dbias);
@@ -4947,14 +4960,14 @@ int hecka_batchnorm_act_fwd_f32(const float* x, const float* res, int G, int N, 
                                 int relu, float* y, float* save_mean, float* save_rstd, float* batch_var, float* ymax,
                                 void* stream) {
   return hecka_batchnorm_act_fwd_packed_f32(x, res, G, N, C, S, weight, bias, C, run_mean, run_var, training, eps, relu, y,
-                                            save_mean, save_rstd, batch_var, ymax, nullptr, nullptr, 0.f, stream);
+                                            save_mean, save_rstd, batch_var, ymax, nullptr, nullptr, 0.f, nullptr, stream);
 }
 
 int hecka_batchnorm_act_fwd_packed_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
                                        const float* bias, int wstride, const float* run_mean, const float* run_var,
                                        int training, float eps, int relu, float* y, float* save_mean, float* save_rstd,
                                        float* batch_var, float* ymax, float* run_mean_upd, float* run_var_upd, float factor,
-                                       void* stream) {
+                                       unsigned char* mask, void* stream) {
   clear_error();
   if (wstride < C || (!run_mean_upd) != (!run_var_upd) || (run_mean_upd && !training))
     return fail(HECKA_EINVAL, "batchnorm_act_fwd: bad affine stride / running-statistics update outside training%s");
@@ -4968,7 +4981,8 @@ int hecka_batchnorm_act_fwd_packed_f32(const float* x, const float* res, int G, 
   hipLaunchKernelGGL(batchnorm_fwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, x, N, C, S, weight, bias,
                      run_mean, run_var, training, eps, y, save_mean, save_rstd, batch_var, res, relu,
                      reinterpret_cast<unsigned*>(ymax),
-                     BnExtra{wstride, run_mean_upd, run_var_upd, factor, (float)((double)N * S / (double)std::max<long long>((long long)N * S - 1, 1))});
+                     BnExtra{wstride, run_mean_upd, run_var_upd, factor,
+                             (float)((double)N * S / (double)std::max<long long>((long long)N * S - 1, 1)), mask});
   return check_launch("batchnorm_act_fwd");
 }
 
@@ -4977,25 +4991,26 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
                                 int training, float* dx, float* dres, float* dweight, float* dbias, float* dxmax,
                                 void* stream) {
   return hecka_batchnorm_act_bwd_packed_f32(dy, x, y, save_mean, save_rstd, weight, C, G, N, C, S, training, dx, dres, dweight,
-                                            dbias, dxmax, stream);
+                                            dbias, dxmax, nullptr, stream);
 }
 
 int hecka_batchnorm_act_bwd_packed_f32(const float* dy, const float* x, const float* y, const float* save_mean,
                                        const float* save_rstd, const float* weight, int wstride, int G, int N, int C,
                                        long long S, int training, float* dx, float* dres, float* dweight, float* dbias,
-                                       float* dxmax, void* stream) {
+                                       float* dxmax, const unsigned char* mask, void* stream) {
   clear_error();
   if (wstride < C) return fail(HECKA_EINVAL, "batchnorm_act_bwd: bad affine stride%s");
   if (!dy || !x || !save_mean || !save_rstd) return fail(HECKA_EINVAL, "batchnorm_act_bwd: null pointer%s");
   if (dxmax && !dx) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dxmax needs dx%s");
   if (G <= 0 || G > 65535 || N <= 0 || C <= 0 || S <= 0) return fail(HECKA_EINVAL, "batchnorm_act_bwd: size out of range%s");
-  if (dres && !y) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dres needs the forward output y%s");
+  if (dres && !y && !mask) return fail(HECKA_EINVAL, "batchnorm_act_bwd: dres needs the forward output y or its mask%s");
   if (S % 4 != 0 || !aligned16(x) || !aligned16(dy) || (y && !aligned16(y)) || (dx && !aligned16(dx)) || (dres && !aligned16(dres)))
     return fail(HECKA_EINVAL, "batchnorm_act_bwd: needs S %% 4 == 0 and 16-byte alignment%s");
   if (dxmax && hipMemsetAsync(dxmax, 0, (size_t)G * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return check_launch("batchnorm_act_bwd (memset)");
   hipLaunchKernelGGL(batchnorm_bwd_vec_kernel, dim3(C, G), dim3(256), 0, (hipStream_t)stream, dy, x, save_mean, save_rstd,
-                     weight, N, C, S, training, dx, dweight, dbias, y, dres, reinterpret_cast<unsigned*>(dxmax), wstride);
+                     weight, N, C, S, training, dx, dweight, dbias, mask ? nullptr : y, dres, reinterpret_cast<unsigned*>(dxmax),
+                     wstride, mask);
   return check_launch("batchnorm_act_bwd");
 }
 

@@ -56,8 +56,8 @@ SIGNATURES = {
     'hecka_bgemm_x3_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'hecka_bgemm_x3_f32': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, ctypes.c_float, _vp, _vp, _i, _vp, _sz, _vp]),
     'hecka_batchnorm_act_fwd_f32': (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'hecka_batchnorm_act_fwd_packed_f32': (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp]),
-    'hecka_batchnorm_act_bwd_packed_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'hecka_batchnorm_act_fwd_packed_f32': (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp]),
+    'hecka_batchnorm_act_bwd_packed_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'hecka_conv_direct_eligible': (_i, [_i, _i, _i, _i]),
     'hecka_conv_direct_f32': (_i, [_vp, _ll, _vp, _vp, ctypes.c_float, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'hecka_conv_direct_wgrad_f32': (_i, [_vp, _ll, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -27,6 +27,7 @@ class _Knobs(object):
         self.conv_tapmajor = on('HECKA_CONV_TAPMAJOR')    # implicit convolutions with K ordered (tap, channel) where 16 | C
         self.conv_keep_cols_gb = float(env('HECKA_CONV_KEEP_COLS_GB', '8'))
         self.bn_fuse = on('HECKA_BN_FUSE')                # norm + residual + relu in one launch
+        self.bn_mask = on('HECKA_BN_MASK')                # the fused norm's backward reads a byte-per-quad relu mask instead of y
         self.sampler_torch = set(filter(None, env('HECKA_SAMPLER_TORCH', '').split(',')))
         self.shard_mode = env('HECKA_SHARD_MODE', 'slice')
         self.shard_exchange = env('HECKA_SHARD_EXCHANGE', 'a2a')

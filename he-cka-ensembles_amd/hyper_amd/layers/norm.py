@@ -123,14 +123,17 @@ class BatchedBatchNormAct(torch.autograd.Function):
         mean = torch.empty((M, C), device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         var = torch.empty_like(mean) if training and upd is None else None
+        # all the backward needs of y is the relu's sign: one byte per four outputs instead of y in both of its sweeps
+        mask = (torch.empty((x.numel() // 4,), device=x.device, dtype=torch.uint8)
+                if relu and knobs.bn_mask and any(ctx.needs_input_grad[:4]) else None)
         _lib.check(_lib.lib().hecka_batchnorm_act_fwd_packed_f32(
             x.data_ptr(), ptr(res), M, N, C, S, w_ptr, b_ptr, wstride, ptr(run_mean), ptr(run_var), int(training), float(eps),
             int(bool(relu)), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ptr(var), ymax.data_ptr(),
             upd[0].data_ptr() if upd is not None else None, upd[1].data_ptr() if upd is not None else None,
-            float(upd[2]) if upd is not None else 0.0, torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
+            float(upd[2]) if upd is not None else 0.0, ptr(mask), torch.cuda.current_stream().cuda_stream), 'batchnorm_act_fwd')
         tag_absmax(y, ymax)      # the convolution that reads y next takes its operand scale from here
-        ctx.save_for_backward(x, mean, rstd, w, y if relu else None)
-        ctx.cfg = (training, S, weight is not None, bias is not None or packed, res is not None, packed)
+        ctx.save_for_backward(x, mean, rstd, w, y if relu and mask is None else None, mask)
+        ctx.cfg = (training, S, weight is not None, bias is not None or packed, res is not None, packed, bool(relu))
         if var is None:
             var = mean if upd is not None else mean.new_zeros(())
         ctx.mark_non_differentiable(mean, var)
@@ -138,15 +141,15 @@ class BatchedBatchNormAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        x, mean, rstd, w, y = ctx.saved_tensors
-        training, S, has_w, has_b, has_res, packed = ctx.cfg
+        x, mean, rstd, w, y, mask = ctx.saved_tensors
+        training, S, has_w, has_b, has_res, packed, relu = ctx.cfg
         M, N, C = x.shape[:3]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dxmax = torch.empty((M,), device=x.device, dtype=torch.float32) if dx is not None else None
         dres = None
         if has_res and ctx.needs_input_grad[1]:
-            dres = torch.empty_like(x) if y is not None else dy      # no relu: the residual's gradient is dy itself
+            dres = torch.empty_like(x) if relu else dy      # no relu: the residual's gradient is dy itself
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         if packed:
             dw = torch.empty((M, 2 * C), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
@@ -158,7 +161,7 @@ class BatchedBatchNormAct(torch.autograd.Function):
             dw_ptr, db_ptr, wstride = ptr(dw), ptr(db), C
         _lib.check(_lib.lib().hecka_batchnorm_act_bwd_packed_f32(
             dy.data_ptr(), x.data_ptr(), ptr(y), mean.data_ptr(), rstd.data_ptr(), ptr(w), wstride, M, N, C, S, int(training),
-            ptr(dx), ptr(dres) if y is not None else None, dw_ptr, db_ptr, ptr(dxmax),
+            ptr(dx), ptr(dres) if relu else None, dw_ptr, db_ptr, ptr(dxmax), ptr(mask),
             torch.cuda.current_stream().cuda_stream), 'batchnorm_act_bwd')
         if dx is not None:
             tag_absmax(dx, dxmax)    # dx is the output gradient of the convolution in front of this norm

@@ -403,16 +403,18 @@ int hecka_batchnorm_act_bwd_f32(const float* dy, const float* x, const float* y,
  * dbias likewise, so their gradients return as one tensor and no copy of either half is made) - and with the running
  * statistics [G,C] updated by the kernel itself in training (run_mean_upd / run_var_upd, may be NULL):
  * rm = (1 - factor) rm + factor mean, rv = (1 - factor) rv + factor var n / (n - 1), n = N S (hyper/layers/norm.py:209-222
- * leaves that to F.batch_norm per member; here it was a dozen [G,C]-sized torch kernels per norm layer, 4 us each). */
+ * leaves that to F.batch_norm per member; here it was a dozen [G,C]-sized torch kernels per norm layer, 4 us each).
+ * mask (may be NULL; G N C S / 4 bytes): the forward writes one byte per four outputs, bit e = y[4 i + e] > 0; the backward,
+ * given it, does not read y (all it needs of y is the relu's sign: 1 / 16 of the bytes in each of its two sweeps). */
 int hecka_batchnorm_act_fwd_packed_f32(const float* x, const float* res, int G, int N, int C, long long S, const float* weight,
                                        const float* bias, int wstride, const float* run_mean, const float* run_var,
                                        int training, float eps, int relu, float* y, float* save_mean, float* save_rstd,
                                        float* batch_var, float* ymax, float* run_mean_upd, float* run_var_upd, float factor,
-                                       void* stream);
+                                       unsigned char* mask, void* stream);
 int hecka_batchnorm_act_bwd_packed_f32(const float* dy, const float* x, const float* y, const float* save_mean,
                                        const float* save_rstd, const float* weight, int wstride, int G, int N, int C,
                                        long long S, int training, float* dx, float* dres, float* dweight, float* dbias,
-                                       float* dxmax, void* stream);
+                                       float* dxmax, const unsigned char* mask, void* stream);
 
 /* Direct convolution for FEW channels (hyper/layers/conv.py:492-502 loops F.conv2d over the members; LeNet-5's convs are
  * 1 -> 6 and 6 -> 16 channels, 5x5): unit stride, no dilation, zero padding `pad` on both axes, C <= 16, O <= 16, kernel

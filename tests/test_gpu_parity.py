@@ -1553,6 +1553,39 @@ def test_packed_batchnorm_equals_the_unpacked_launch(relu, with_res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('with_res', [True, False])
+def test_batchnorm_relu_mask_equals_reading_the_output(with_res, monkeypatch):
+    """The fused norm's backward reads the forward's byte-per-four-outputs relu mask instead of y (HECKA_BN_MASK, default on):
+    bit-equal gradients to the launch that reads y (HECKA_BN_MASK=0) - zeros of the relu included (a channel driven fully
+    negative)."""
+    from hyper_amd.layers.norm import BatchedBatchNormAct
+    dev = torch.device('cuda:0')
+    torch.manual_seed(9)
+    M, N, C, H = 2, 16, 8, 8
+    x0 = torch.randn(M, N, C, H, H, device=dev)
+    r0 = torch.randn_like(x0) if with_res else None
+    flat0 = torch.randn(M, 2 * C, device=dev)
+    flat0[:, 0] = 0.0
+    flat0[:, C] = -1.0                      # channel 0: weight 0, bias -1 - every output of it is clipped (without a residual)
+    up = torch.randn_like(x0)
+    res = []
+    for setting in (None, '0'):
+        if setting is not None:
+            monkeypatch.setenv('HECKA_BN_MASK', setting)
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if r0 is not None else None
+        flat = flat0.clone().requires_grad_(True)
+        y, _, _ = BatchedBatchNormAct.apply(x, r, flat, None, None, None, True, 1e-5, True, True, None)
+        (y * up).sum().backward()
+        res.append((y.detach(), x.grad, r.grad if r is not None else None, flat.grad))
+    for u, v in zip(*res):
+        assert (u is None and v is None) or torch.equal(u, v)
+    yd = torch.relu(torch.nn.functional.batch_norm(x0[0].double(), None, None, flat0[0, :C].double(), flat0[0, C:].double(), True, 0.0, 1e-5)
+                    + (r0[0].double() if with_res else 0.0))
+    assert float((res[0][0][0].double() - yd).abs().max()) <= 1e-5 * float(yd.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('k,stride,pad,H,W,N,C,O,shared', [
     ((3, 3), (2, 2), (1, 1), 16, 16, 8, 64, 128, False),     # a ResNet stage transition
     ((1, 1), (2, 2), (0, 0), 16, 16, 8, 64, 128, False),     # its 1 x 1 shortcut

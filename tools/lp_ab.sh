@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd $R
-timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py tests/test_knobs.py -x -q -m gpu --timeout 120 --timeout-method thread -k "conv or single_product or resnet or train_step or tapmajor" > $O/lp_tests.log 2>&1 || { tail -30 $O/lp_tests.log; exit 1; }
+timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py tests/test_knobs.py -x -q -m gpu --timeout 120 --timeout-method thread -k "conv or single_product or resnet or train_step or tapmajor or batchnorm or norm" > $O/lp_tests.log 2>&1 || { tail -30 $O/lp_tests.log; exit 1; }
 tail -3 $O/lp_tests.log
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 python $R/tools/train_bench.py cifar --steps 20 --warmup 5 > $O/lp3.txt 2>/dev/null || exit 1
