@@ -138,6 +138,12 @@ template <class P, class = void>
 struct implicit_nt : std::false_type {};
 template <class P>
 struct implicit_nt<P, std::void_t<decltype(P::kImplicitNT)>> : std::bool_constant<P::kImplicitNT> {};
+// ... whose B quad is four CONSECUTIVE elements in memory (Pro::kQuadB = true): ONE 16-byte load at pro.btoffq(SET, i); the
+// prologue keeps what to zero of it (elements pushed over an image row's edge) per register set and applies it in stageB.
+template <class P, class = void>
+struct quad_nt : std::false_type {};
+template <class P>
+struct quad_nt<P, std::void_t<decltype(P::kQuadB)>> : std::bool_constant<P::kQuadB> {};
 
 // Product tile out[i,j] = sum_k A[i,k] B(k,j).  RAGGED = false: interior tiles only (rows/cols multiples of the tile,
 // (kend - kbeg) a multiple of 16, 16-byte aligned A rows).  RAGGED = true: any row / column count and any k range that is
@@ -280,6 +286,8 @@ struct GemmTileX6 {
             else
               rb[S][i][c] = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsB, (int)vo, so, 0));
           }
+        } else if constexpr (quad_nt<Pro>::value) {
+          rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)pro.btoffq(SET, i), 0, 0));
         } else if constexpr (implicit_nt<Pro>::value) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)

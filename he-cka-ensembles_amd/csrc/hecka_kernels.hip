@@ -98,6 +98,7 @@ struct Config {
   bool gram_pair;         // HECKA_GRAM_PAIR   (1): all-layers Gram on the paired 128 x 256 tiles (0: 128 x 128 tiles)
   int gram_spec;          // HECKA_GRAM_SPEC   (1): speculative Gram (sampled shift + row-centring) where eligible AND worth it
                           // (0: always the exact column-mean pass; 2: wherever the shape is eligible - tests)
+  bool wgrad_quad;        // HECKA_WGRAD_QUAD   (1): implicit weight gradient loads a tap's four consecutive pixels as one quad
   int layer_products;     // HECKA_LAYER_PRODUCTS (3): products per multiply of the layer GEMMs / convolutions on the fp16 tile
                           // (3: h.h + h.l + l.h, fp32-grade; 1: h.h only - operands rounded to fp16 after their
                           // power-of-two scale, fp32 accumulation: the 16-bit compute mode, hecka_set_layer_products)
@@ -118,6 +119,7 @@ static Config read_config() {
   c.gram_pair = num("HECKA_GRAM_PAIR", 1) != 0;
   c.gram_spec = (int)num("HECKA_GRAM_SPEC", 1);
   c.layer_products = num("HECKA_LAYER_PRODUCTS", 3) == 1 ? 1 : 3;
+  c.wgrad_quad = num("HECKA_WGRAD_QUAD", 1) != 0;
   return c;
 }
 static Config g_config = read_config();
@@ -2116,7 +2118,42 @@ struct ConvWgradPro {
   }
 };
 
-template <int TM, bool LOW = true>
+// Unit stride along the row (sw = 1): the four positions of the thread's quad read four CONSECUTIVE input pixels for a tap -
+// one 16-byte load (dword aligned) instead of four dword gathers.  A wave-load of the element-wise form touched the 64-byte
+// pieces of 16 tap rows to fetch 256 bytes, four times over for the four elements: the texture path's line rate, not the
+// MFMAs, bounded the weight gradients (a CU finished a k-tile every 730 - 860 cycles against 190 - 380 of MFMA).  Elements a
+// tap column pushes over the row's edge are zeroed when the quad is staged (a mask per register set and row, kept from the
+// load); a tap row outside the image sends the whole quad out of range; the one quad whose shifted start would lie BEFORE
+// the buffer (image 0, channel 0, row 0, a tap to the left) is loaded from the buffer's start and shifted when staged.
+struct ConvWgradProQ : ConvWgradPro {
+  static constexpr bool kQuadB = true;
+  unsigned msk[2][2];       // [register set][row i]: bit e = element e is a pixel of the row; bits 4.. = shift to the right
+  template <class T> __device__ __forceinline__ unsigned btoffq(T, int i) {
+    const int hh = h0 + bdi[i], ws = w0 + bdj[i];
+    const bool rok = (unsigned)hh < (unsigned)H;
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m |= ((unsigned)(ws + e) < (unsigned)W ? 1u : 0u) << e;
+    const int eidx = (int)(bq4 >> 2) + boff[i];        // (element indices stay below 2^30)
+    const int back = eidx < 0 ? -eidx : 0;             // 1 .. 3 for that one quad, else 0
+    msk[T::value][i] = m | ((unsigned)back << 4);
+    return rok ? (unsigned)(eidx + back) * 4u : 0xFFFFFFF0u;
+  }
+  template <class T> __device__ __forceinline__ void stageB(T, f32x4& v, int i) {
+    const unsigned m = msk[T::value][i];
+    if (m >> 4) {
+      const int k = (int)(m >> 4);
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 1; e < 4; ++e) u[e] = e - k >= 0 ? (e - k == 0 ? v[0] : e - k == 1 ? v[1] : v[2]) : 0.f;
+      v = u;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((m >> e) & 1u) ? v[e] * sb : 0.f;
+  }
+};
+
+template <int TM, bool LOW = true, bool QUAD = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                     float* __restrict__ out, const int2* __restrict__ tab,
                                                                     int O, int Rp, long long strideX, int N, int C, int H,
@@ -2124,7 +2161,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
                                                                     const float* __restrict__ amaxB, int amaxB_stride,
                                                                     float alpha, int tilesM, int tilesN, int kchunk,
                                                                     long long slab, int Ho, int Wo, int sh, int sw) {
-  using Tile = GemmTileX6<TM, 128, false, ConvWgradPro, 1, true, kElemF32, kElemF32, LOW, LOW>;
+  using Pro = std::conditional_t<QUAD, ConvWgradProQ, ConvWgradPro>;
+  using Tile = GemmTileX6<TM, 128, false, Pro, 1, true, kElemF32, kElemF32, LOW, LOW>;
   __shared__ typename Tile::Smem sm;
   const int per = tilesM * tilesN;
   const int b = blockIdx.x / per, tl = blockIdx.x % per;
@@ -2133,7 +2171,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_x3_kernel(const float*
   const int kbeg = blockIdx.y * kchunk;
   int kend = kbeg + kchunk;
   if (kend > Q) kend = Q;
-  ConvWgradPro pro;
+  Pro pro;
   pro.sa = pow2_scale(amaxA[b], 14);
   pro.sb = pow2_scale(amaxB[(size_t)b * amaxB_stride], 14);
   pro.O = O; pro.C = C; pro.H = H; pro.W = W; pro.S = S;
@@ -4765,10 +4803,11 @@ static int conv_wgrad_nsplit(int batch, int O, int Rp, long long Q) {
   if (want < 2) return 1;
   // two workgroups per CU: of the split counts around `want`, take the one whose grid fills its last scheduling round
   // best (90 tiles x 12 = 1080 workgroups are three rounds of 512 slots, the third a tenth full; x 11 = 990 are two)
-  const long long slots = 2ll * device_cus();
+  // (workgroups per CU by registers: the 64-row tile's kernel takes 146 VGPRs - three waves per SIMD -, the 128-row one's 226)
+  const long long slots = (O % 128 ? 3ll : 2ll) * device_cus();
   long long best = want;
   double best_eff = 0.0;
-  for (long long ns = std::max(2ll, want - want / 4); ns <= std::min(maxs, want + (want + 1) / 2); ++ns) {
+  for (long long ns = std::max(2ll, want / 2); ns <= std::min(maxs, want + (want + 1) / 2); ++ns) {
     const long long g = tiles * ns, rounds = (g + slots - 1) / slots;
     const double eff = (double)g / (double)(rounds * slots);
     if (eff > best_eff + 0.04) { best_eff = eff; best = ns; }   // (more splits = more slabs to reduce: only for a clear gain)
@@ -4821,12 +4860,16 @@ int hecka_conv_wgrad_x3_strided_f32(const float* dY, const float* X, float* dW, 
   const long long slab = (long long)batch * O * Rp;
   const int2* t2 = reinterpret_cast<const int2*>(tab);
   const bool low = config().layer_products != 1;
-#define HECKA_WX3(TMV, LOWV) \
-  hipLaunchKernelGGL((conv_wgrad_x3_kernel<TMV, LOWV>), grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, \
+  const bool quad = sw == 1 && config().wgrad_quad;      // four consecutive input pixels per quad: one 16-byte load
+#define HECKA_WX3_(TMV, LOWV, QV) \
+  hipLaunchKernelGGL((conv_wgrad_x3_kernel<TMV, LOWV, QV>), grid, dim3(kThreads), 0, st, dY, X, out, t2, O, Rp, strideX, N, C, H, W, \
                      amaxA, amaxB, amaxB_stride, alpha, tilesM, tilesN, kchunk, slab, Ho, Wo, sh, sw)
+#define HECKA_WX3(TMV, LOWV) \
+  do { if (quad) HECKA_WX3_(TMV, LOWV, true); else HECKA_WX3_(TMV, LOWV, false); } while (0)
   if (tm == 128) { if (low) HECKA_WX3(128, true); else HECKA_WX3(128, false); }
   else { if (low) HECKA_WX3(64, true); else HECKA_WX3(64, false); }
 #undef HECKA_WX3
+#undef HECKA_WX3_
   if (int rc = check_launch("conv_wgrad_x3")) return rc;
   if (ns > 1) {
     // (slab = batch O Rp with Rp % 128 == 0: whole quads; ws and dW 16-byte aligned - checked below / by the tile)

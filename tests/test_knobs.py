@@ -103,10 +103,12 @@ def test_streamed_dx_launch_is_bit_equal_to_a_workgroup_per_tile(M, B, Ps, grid,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('knob,value,stride', [('HECKA_CONV_IMPLICIT', '0', 1), ('HECKA_CONV_KEEP_COLS_GB', '0', 1),
-                                               ('HECKA_CONV_TAPMAJOR', '0', 1), ('HECKA_CONV_TAPMAJOR', '0', 2)])
+                                               ('HECKA_CONV_TAPMAJOR', '0', 1), ('HECKA_CONV_TAPMAJOR', '0', 2),
+                                               ('HECKA_WGRAD_QUAD', '0', 1)])
 def test_conv_knob_alternative_matches_default(knob, value, stride, monkeypatch):
     """Implicit-GEMM convolution off (explicit im2col / col2im for every conv) / gathered patches never kept for backward /
-    the implicit GEMMs with K ordered (channel, tap) - a range check per gathered element - instead of (tap, channel)."""
+    the implicit GEMMs with K ordered (channel, tap) - a range check per gathered element - instead of (tap, channel) / the
+    implicit weight gradient gathering its patches element by element instead of four consecutive pixels per load."""
     from hyper_amd.layers.conv import BatchedConv2d
     dev = torch.device('cuda:0')
     torch.manual_seed(5)
