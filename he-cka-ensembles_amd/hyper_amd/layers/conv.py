@@ -179,11 +179,11 @@ def _dgrad_s2(W, dy, geom, N, H, Wd, Ho, Wo, scale, wmax, dymax):
         if not I or not J or U == 0 or V == 0:
             continue
         K = O * len(I) * len(J)
-        if tap:
-            A = Wp[:, :, I][:, :, :, J].reshape(M, C, K).contiguous()
+        if tap:      # (I, J: every second tap - basic slices, one copy)
+            A = Wp[:, :, I[0]::2, J[0]::2].reshape(M, C, K).contiguous()
             tab = _tap_tab(O, Ho, Wo, [(ti, tj) for ti in di for tj in dj], dy.device)
         else:
-            A = Wp[:, :, :, I][:, :, :, :, J].reshape(M, C, K).contiguous()
+            A = Wp[:, :, :, I[0]::2, J[0]::2].reshape(M, C, K).contiguous()
             key = ('dgrad2', O, Ho, Wo, tuple(di), tuple(dj), str(dy.device))
             if key not in _TABS:
                 o = torch.arange(O, dtype=torch.int64).view(O, 1, 1)
