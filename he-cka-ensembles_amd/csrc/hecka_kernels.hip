@@ -2910,8 +2910,29 @@ __device__ __forceinline__ BnMap bn_map(long long S) {
 // slab of the first ResNet stage is 512 KB for ONE workgroup and the grid (channels x members) is 2.5 workgroups per CU:
 // with one float4 in flight per thread the sweeps ran at 3.4 TB/s.  When a thread owns one float4 per image (S / 4 a power
 // of two <= 256: every shipped shape) four images' loads are issued before the first is used.
-template <class Load, class Use>
+// REV: the thread's images in DESCENDING order - the second sweep of a kernel starts with what the first read last.  The
+// slabs in flight (2.5 workgroups per CU x 0.5 - 1 MB in the first stage) are about the size of the 256 MB Infinity Cache:
+// re-read in the same order, every piece has been evicted by the time its turn comes (LRU); backwards, the most recent
+// part is still there.
+template <bool REV = false, class Load, class Use>
 __device__ __forceinline__ void bn_sweep(const BnMap& m, int N, size_t base, size_t nstride, Load&& load, Use&& use) {
+  if (REV && m.s4 == m.tpi) {
+    const size_t o0 = base + 4 * (size_t)m.si, step = (size_t)m.ipp * nstride;
+    int k = m.ni < N ? (N - m.ni + m.ipp - 1) / m.ipp : 0;      // images of this thread: ni, ni + ipp, ..
+    size_t o = o0 + ((size_t)m.ni + (size_t)(k > 0 ? k - 1 : 0) * m.ipp) * nstride;
+    for (; k >= 4; k -= 4, o -= 4 * step) {
+      auto v0 = load(o);
+      auto v1 = load(o - step);
+      auto v2 = load(o - 2 * step);
+      auto v3 = load(o - 3 * step);
+      use(o, v0);
+      use(o - step, v1);
+      use(o - 2 * step, v2);
+      use(o - 3 * step, v3);
+    }
+    for (; k > 0; --k, o -= step) use(o, load(o));
+    return;
+  }
   if (m.s4 == m.tpi) {
     const size_t o0 = base + 4 * (size_t)m.si, step = (size_t)m.ipp * nstride;
     int n = m.ni;
@@ -2998,7 +3019,7 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_vec_kernel(const float* __r
   const float w = weight ? weight[(size_t)g * ex.wstride + c] : 1.0f, b = bias ? bias[(size_t)g * ex.wstride + c] : 0.0f;
   const float sc = w * rstd, sh = b - mean * sc;
   float amax = 0.f;
-  bn_sweep(m, N, base, nstride,
+  bn_sweep<true>(m, N, base, nstride,
            [&](size_t o) {
              BnPair p;
              p.v = *reinterpret_cast<const f32x4*>(x + o);
@@ -3077,7 +3098,7 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_vec_kernel(const float* __r
   const float w = weight ? weight[(size_t)g * wstride + c] : 1.0f;
   const float k = w * rstd, m1 = training ? (float)(sdy / (double)cnt) : 0.f, m2 = training ? (float)(sdx / (double)cnt) : 0.f;
   float amax = 0.f;
-  bn_sweep(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
+  bn_sweep<true>(m, N, base, nstride, load3, [&](size_t o, const BnTriple& p) {
     f32x4 d = p.d;
     if (masked) {
 #pragma unroll
