@@ -2477,42 +2477,75 @@ __device__ __forceinline__ unsigned f2key(float f) {
 }
 __global__ __launch_bounds__(1024) void rbf_bandwidth_kernel(const float* __restrict__ G, int B, float param,
                                                             float* __restrict__ hband) {
-  __shared__ unsigned hist[256];
+  // One workgroup per member.  Per pass: a histogram per WAVE (the keys of one member cluster in a few bins of the leading
+  // byte: with one shared histogram ten thousand LDS atomics queued on one address), merged by 256 threads; the bin that
+  // holds rank k found by ONE wave with a shuffle scan (a single thread walking 256 bins in LDS was 8 us per pass: the
+  // launch took 57 us for the toy configuration's 100 x 100 Grams, a quarter of its training step).  The element's row and
+  // column advance incrementally - no 64-bit division per element.
+  __shared__ unsigned hist[16][256];
   __shared__ unsigned sel_prefix, sel_k;
   const int m = blockIdx.x;
   const float* g = G + (size_t)m * B * B;
   const long long n = (long long)B * B;
-  if (threadIdx.x == 0) {
+  const int t = threadIdx.x, wave = t >> 6;
+  if (t == 0) {
     sel_prefix = 0u;
     sel_k = (unsigned)((n - 1) / 2);
   }
+  const int a0 = t / B, b0 = t - a0 * B;
+  const int da = 1024 / B, db = 1024 - da * B;
   unsigned mask = 0u;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    for (int q = t; q < 16 * 256; q += 1024) (&hist[0][0])[q] = 0u;
     __syncthreads();
     const unsigned prefix = sel_prefix;
-    for (long long e = threadIdx.x; e < n; e += 1024) {
-      const int a = (int)(e / B), b = (int)(e - (long long)a * B);
+    int a = a0, b = b0;
+    for (long long e = t; e < n; e += 1024) {
       float d = -2.0f * g[e] + g[(size_t)a * B + a];
       d += g[(size_t)b * B + b];
       const unsigned key = f2key(d);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255u], 1u);
+      a += da;
+      b += db;
+      if (b >= B) { b -= B; ++a; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned k = sel_k, bin = 0;
-      for (; bin < 256; ++bin) {
-        if (k < hist[bin]) break;
-        k -= hist[bin];
+    if (t < 256) {
+      unsigned c = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) c += hist[w][t];
+      hist[0][t] = c;
+    }
+    __syncthreads();
+    if (t < 64) {
+      const unsigned c0 = hist[0][4 * t], c1 = hist[0][4 * t + 1], c2 = hist[0][4 * t + 2], c3 = hist[0][4 * t + 3];
+      const unsigned sum = c0 + c1 + c2 + c3;
+      unsigned incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o);
+        if (t >= o) incl += up;
       }
-      sel_k = k;
-      sel_prefix = prefix | (bin << shift);
+      const unsigned ex = incl - sum, k = sel_k;
+      if (k >= ex && k < incl) {        // exactly one lane: rank k lies in its four bins
+        unsigned r = k - ex;
+        unsigned bin = 4u * t;
+        if (r >= c0) {
+          r -= c0; ++bin;
+          if (r >= c1) {
+            r -= c1; ++bin;
+            if (r >= c2) { r -= c2; ++bin; }
+          }
+        }
+        sel_k = r;
+        sel_prefix = prefix | (bin << shift);
+      }
     }
     mask |= 0xFFu << shift;
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (t == 0) {
     const unsigned key = sel_prefix;
     const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
     const float med = __uint_as_float(u);
